@@ -1,0 +1,79 @@
+"""ctypes binding of libpings_hip.so (the C ABI declared in include/pings_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call is
+made with tensors that are not on a HIP device, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libpings_hip.so"
+HEADER = PKG.parent / "include" / "pings_hip.h"
+
+_lib = None
+
+c_fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class PingsHipError(RuntimeError):
+    pass
+
+
+def header_symbols() -> list[str]:
+    """Names of every PINGS_API function declared in include/pings_hip.h."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return re.findall(r"PINGS_API\s+[\w\s\*]+?\b(pings_\w+)\s*\(", txt)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise PingsHipError(
+                f"{LIB_PATH} is missing: build it with `python -m pings_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
+        _lib = C.CDLL(str(LIB_PATH))
+        _declare(_lib)
+    return _lib
+
+
+def _declare(l: C.CDLL) -> None:
+    l.pings_abi_version.restype = C.c_int
+    l.pings_last_error.restype = C.c_char_p
+    l.pings_ssim_partials_count.restype = C.c_size_t
+    l.pings_ssim_partials_count.argtypes = [C.c_int] * 3
+    l.pings_ssim_forward.restype = C.c_int
+    l.pings_ssim_forward.argtypes = [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    l.pings_ssim_backward.restype = C.c_int
+    l.pings_ssim_backward.argtypes = [c_fp, c_fp, C.c_int, C.c_int, C.c_int,
+                                      c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().pings_last_error().decode(errors="replace")
+        raise PingsHipError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t: torch.Tensor | None):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PingsHipError(
+            "pings_amd ops run on the HIP device only (got a CPU tensor); "
+            "there is no CPU fallback")
+    if not t.is_contiguous():
+        raise PingsHipError("pings_amd internal error: non-contiguous tensor at the C ABI")
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream

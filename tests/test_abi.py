@@ -1,0 +1,27 @@
+"""The C-ABI library loads and exports every symbol include/pings_hip.h declares."""
+import ctypes
+
+from pings_amd import _lib
+
+
+def test_header_declares_symbols():
+    names = _lib.header_symbols()
+    assert "pings_abi_version" in names and "pings_ssim_forward" in names
+    assert len(names) == len(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    missing = [n for n in _lib.header_symbols() if not hasattr(L, n)]
+    assert not missing, f"symbols declared in include/pings_hip.h but not exported: {missing}"
+    assert L.pings_abi_version() >= 1
+    assert L.pings_last_error() is not None
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    L = _lib.lib()
+    # null pointers / empty shapes are rejected before any GPU work is attempted
+    st = L.pings_ssim_forward(None, None, 3, 8, 8, 0, None, None, None, None, None, None)
+    assert st == 1
+    assert b"null" in L.pings_last_error()
+    assert L.pings_ssim_partials_count(0, 8, 8) == 0
