@@ -41,9 +41,12 @@ class _FusedSSIM(torch.autograd.Function):
                                   _lib.ptr(partials), _lib.stream_ptr(a.device))
         _lib.check(st, "pings_ssim_forward")
         ctx.need_grad = need_grad
+        res = out.reshape(())
         if need_grad:
             ctx.save_for_backward(a, b, maps)
-        return out.reshape(())
+        else:
+            ctx.mark_non_differentiable(res)
+        return res
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
