@@ -1,0 +1,105 @@
+// Shared definitions of the Gaussian(-surfel) rasteriser kernels.
+//
+// HBM layout (all buffers caller-owned, carved out of three opaque blobs):
+//   geom blob   (per Gaussian)  rec[P][4] float4  : {mx,my,opacity,pz} {conic_x,conic_y,conic_z,rz}
+//                                                    {r,g,b,q} {nx,ny,nz,-}
+//                               rect[P]   uint4   : {inst_base, xmin|ymin<<16, xmax|ymax<<16, tiles}
+//                               depth keys / ids (+ sorted copies), tiles-in-depth-order, their scan,
+//                               radix-sort / scan scratch
+//   binning blob (per instance) tile keys / Gaussian ids (+ sorted copies), ranges[num_tiles] uint2, scratch
+//   image blob   (per pixel)    final_T[HW] float, n_contrib[HW] uint32
+//
+// Instances (Gaussian x touched tile) are created in DEPTH order (the P Gaussians are
+// radix-sorted by their fp32 view depth first) and then stably radix-sorted by tile id
+// only, so the final order inside a tile is (depth, Gaussian index) — the same order a
+// 64-bit (tile<<32 | depth) key sort gives, at a quarter of the sort traffic.
+#pragma once
+#include "common.hpp"
+
+namespace pings {
+namespace raster {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;  // 256 threads = 4 waves; wave w owns rows 4w..4w+3
+constexpr float NEAR_Z = 0.2f;
+constexpr float LOWPASS = 0.3f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_EPS = 1e-4f;
+constexpr float DEPTH_ALPHA_EPS = 1e-10f;
+constexpr float DEN_EPS = 1e-6f;
+constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
+
+constexpr int MODE_SURFEL = 0;
+constexpr int MODE_3DGS = 1;
+
+// 16 floats of per-instance gradient accumulated by the blend backward pass
+// (one 64-B row per (tile, Gaussian) instance, summed per Gaussian afterwards).
+constexpr int GRAD_ROW = 16;
+enum GradSlot {
+  G_MX = 0, G_MY = 1, G_CONX = 2, G_CONY = 3, G_CONZ = 4, G_OPAC = 5,
+  G_R = 6, G_G = 7, G_B = 8, G_NX = 9, G_NY = 10, G_NZ = 11, G_Q = 12, G_PZ = 13,
+  G_ZLO = 14, G_ZHI = 15
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = align_up(off + count * sizeof(T));
+    return p;
+  }
+};
+
+struct GeomState {
+  float4* rec;
+  uint4* rect;
+  uint32_t *depth_key, *depth_key_sorted, *gidx, *gidx_sorted;
+  uint32_t *tiles_sorted, *offsets_sorted;
+  char* temp;
+  size_t temp_bytes;
+  size_t total;
+};
+
+struct BinState {
+  uint32_t *tile_key, *tile_key_sorted, *gval, *point_list;
+  uint2* ranges;
+  char* temp;
+  size_t temp_bytes;
+  size_t total;
+};
+
+struct ImageState {
+  float* final_T;
+  uint32_t* n_contrib;
+  size_t total;
+};
+
+GeomState carve_geom(void* blob, int P);
+BinState carve_binning(void* blob, int64_t I, int num_tiles);
+ImageState carve_image(void* blob, int W, int H);
+
+// wave64 sum through DPP; the total ends up in lane 63.
+__device__ inline float wave_reduce_sum_dpp(float v) {
+  // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+__device__ inline float wave_sum_to_all(float v) {
+  v = wave_reduce_sum_dpp(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+}  // namespace raster
+}  // namespace pings

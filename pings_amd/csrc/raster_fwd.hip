@@ -1,0 +1,605 @@
+// Gaussian(-surfel) rasteriser, forward pass, for gfx950.
+//
+// Pipeline (one HIP stream, no host round trip except the 8-byte instance count):
+//   preprocess_kernel   per Gaussian: camera transform, EWA projection, cull, tile rect,
+//                       64-B blend record, fp32 depth key                     [HBM: 56 B in, 96 B out]
+//   radix sort (P)      Gaussians by depth key (hipcub / rocPRIM)
+//   gather + scan       tiles-per-Gaussian in depth order -> instance offsets
+//   duplicate_kernel    emits (tile id, Gaussian id) instances in depth order  [8 B per instance]
+//   radix sort (I)      STABLE sort by tile id only (ceil(log2(tiles)) bits)    [the only multi-pass
+//                       traffic over the instance list; 32-bit keys instead of 64-bit]
+//   tile_ranges_kernel  [start,end) of every tile in the sorted list
+//   blend_fwd_kernel    one 256-thread workgroup (4 waves) per 16x16 tile; 256 records per round
+//                       are staged in LDS with coalesced 16-B loads and broadcast-read by the
+//                       four waves; front-to-back compositing per pixel, wave-uniform skip of
+//                       Gaussians no lane of the wave sees, workgroup-uniform early exit.
+//   per-Gaussian sums   `contributions` / `n_touched` are reduced per (tile, Gaussian) instance on
+//                       chip (DPP wave sum + LDS), stored once per instance, then summed per
+//                       Gaussian: no global atomics, bitwise reproducible.
+//
+// The arithmetic of preprocess_kernel follows oracle/raster_cpu.py:preprocess op for op
+// (this TU is compiled with -ffp-contract=off; IEEE divide / sqrt), so radii, tile
+// rectangles and the sort order match the fp32 oracle bit for bit.
+#include <hipcub/hipcub.hpp>
+
+#include "raster_common.hpp"
+
+namespace pings {
+namespace raster {
+
+struct KParams {
+  int P, W, H, gx, gy;
+  int front_only;
+  float fx, fy, limx, limy, scale_mod;
+  const float* view;
+  const float* proj_raw;
+  const float* bg;
+  const float* prcp;
+};
+
+// ---------------------------------------------------------------- blob carving
+static size_t sort_temp_bytes(int64_t n) {
+  size_t a = 0, b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  return align_up(a > b ? a : b) + 256;
+}
+
+GeomState carve_geom(void* blob, int P) {
+  Carver c(blob);
+  GeomState g;
+  const size_t n = (size_t)(P > 0 ? P : 1);
+  g.rec = c.take<float4>(4 * n);
+  g.rect = c.take<uint4>(n);
+  g.depth_key = c.take<uint32_t>(n);
+  g.depth_key_sorted = c.take<uint32_t>(n);
+  g.gidx = c.take<uint32_t>(n);
+  g.gidx_sorted = c.take<uint32_t>(n);
+  g.tiles_sorted = c.take<uint32_t>(n);
+  g.offsets_sorted = c.take<uint32_t>(n);
+  g.temp_bytes = sort_temp_bytes((int64_t)n);
+  g.temp = c.take<char>(g.temp_bytes);
+  g.total = c.off;
+  return g;
+}
+
+BinState carve_binning(void* blob, int64_t I, int num_tiles) {
+  Carver c(blob);
+  BinState b;
+  const size_t n = (size_t)(I > 0 ? I : 1);
+  b.point_list = c.take<uint32_t>(n);
+  b.ranges = c.take<uint2>((size_t)num_tiles);
+  b.tile_key = c.take<uint32_t>(n);
+  b.tile_key_sorted = c.take<uint32_t>(n);
+  b.gval = c.take<uint32_t>(n);
+  b.temp_bytes = sort_temp_bytes((int64_t)n);
+  b.temp = c.take<char>(b.temp_bytes);
+  b.total = c.off;
+  return b;
+}
+
+ImageState carve_image(void* blob, int W, int H) {
+  Carver c(blob);
+  ImageState im;
+  im.final_T = c.take<float>((size_t)W * H);
+  im.n_contrib = c.take<uint32_t>((size_t)W * H);
+  im.total = c.off;
+  return im;
+}
+
+// ---------------------------------------------------------------- kernels
+__device__ inline void to_camera(const float* __restrict__ V, float x, float y, float z, float& px,
+                                 float& py, float& pz) {
+  px = ((V[0] * x + V[4] * y) + V[8] * z) + V[12];
+  py = ((V[1] * x + V[5] * y) + V[9] * z) + V[13];
+  pz = ((V[2] * x + V[6] * y) + V[10] * z) + V[14];
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ pos, int N,
+                                                            const float* __restrict__ V,
+                                                            const float* __restrict__ Pm,
+                                                            uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float px, py, pz;
+  to_camera(V, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], px, py, pz);
+  const float hx = ((Pm[0] * px + Pm[4] * py) + Pm[8] * pz) + Pm[12];
+  const float hy = ((Pm[1] * px + Pm[5] * py) + Pm[9] * pz) + Pm[13];
+  const float hw = ((Pm[3] * px + Pm[7] * py) + Pm[11] * pz) + Pm[15];
+  const float pw = 1.0f / (hw + 1e-7f);
+  const float nx = hx * pw, ny = hy * pw;
+  present[i] = (pz > NEAR_Z) && (nx >= -1.3f) && (nx <= 1.3f) && (ny >= -1.3f) && (ny <= 1.3f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    KParams p, const float* __restrict__ means3D, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, float4* __restrict__ rec, uint4* __restrict__ rect,
+    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ gidx, int32_t* __restrict__ radii) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.P) return;
+  const float* V = p.view;
+  const float* Pm = p.proj_raw;
+
+  gidx[g] = (uint32_t)g;
+  // defaults for a culled Gaussian
+  uint32_t key = CULLED_KEY;
+  uint4 rc = make_uint4(0u, 0u, 0u, 0u);
+  int rad = 0;
+
+  float px, py, pz;
+  to_camera(V, means3D[3 * g], means3D[3 * g + 1], means3D[3 * g + 2], px, py, pz);
+  bool ok = pz > NEAR_Z;
+
+  const float hx = ((Pm[0] * px + Pm[4] * py) + Pm[8] * pz) + Pm[12];
+  const float hy = ((Pm[1] * px + Pm[5] * py) + Pm[9] * pz) + Pm[13];
+  const float hw = ((Pm[3] * px + Pm[7] * py) + Pm[11] * pz) + Pm[15];
+  const float pw = 1.0f / (hw + 1e-7f);
+  const float ndx = hx * pw, ndy = hy * pw;
+  const float mx = ((ndx + 1.0f) * (float)p.W - 1.0f) * 0.5f;
+  const float my = ((ndy + 1.0f) * (float)p.H - 1.0f) * 0.5f;
+
+  const float qr = rotations[4 * g], qx = rotations[4 * g + 1], qy = rotations[4 * g + 2],
+              qz = rotations[4 * g + 3];
+  const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz), R01 = 2.0f * (qx * qy - qr * qz),
+              R02 = 2.0f * (qx * qz + qr * qy);
+  const float R10 = 2.0f * (qx * qy + qr * qz), R11 = 1.0f - 2.0f * (qx * qx + qz * qz),
+              R12 = 2.0f * (qy * qz - qr * qx);
+  const float R20 = 2.0f * (qx * qz - qr * qy), R21 = 2.0f * (qy * qz + qr * qx),
+              R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+  const float S0 = p.scale_mod * scales[3 * g], S1 = p.scale_mod * scales[3 * g + 1],
+              S2 = p.scale_mod * scales[3 * g + 2];
+  const float RS[3][3] = {{R00 * S0, R01 * S1, R02 * S2},
+                          {R10 * S0, R11 * S1, R12 * S2},
+                          {R20 * S0, R21 * S1, R22 * S2}};
+  // Wc[a][b] = V[b][a] = V[4*b + a]
+  float Mc[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      Mc[a][k] = (V[a] * RS[0][k] + V[4 + a] * RS[1][k]) + V[8 + a] * RS[2][k];
+
+  const float tx = fminf(p.limx, fmaxf(-p.limx, px / pz)) * pz;
+  const float ty = fminf(p.limy, fmaxf(-p.limy, py / pz)) * pz;
+  const float J00 = p.fx / pz;
+  const float J02 = -(p.fx * tx) / (pz * pz);
+  const float J11 = p.fy / pz;
+  const float J12 = -(p.fy * ty) / (pz * pz);
+  float T0[3], T1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    T0[k] = J00 * Mc[0][k] + J02 * Mc[2][k];
+    T1[k] = J11 * Mc[1][k] + J12 * Mc[2][k];
+  }
+  const float cxx = ((T0[0] * T0[0] + T0[1] * T0[1]) + T0[2] * T0[2]) + LOWPASS;
+  const float cxy = (T0[0] * T1[0] + T0[1] * T1[1]) + T0[2] * T1[2];
+  const float cyy = ((T1[0] * T1[0] + T1[1] * T1[1]) + T1[2] * T1[2]) + LOWPASS;
+  const float det = cxx * cyy - cxy * cxy;
+  ok = ok && (det != 0.0f);
+  const float det_inv = 1.0f / (det != 0.0f ? det : 1.0f);
+  const float conic_x = cyy * det_inv, conic_y = -cxy * det_inv, conic_z = cxx * det_inv;
+  const float mid = 0.5f * (cxx + cyy);
+  const float lam = mid + sqrtf(fmaxf(mid * mid - det, 0.1f));
+  const float radius = ceilf(3.0f * sqrtf(lam));
+  ok = ok && isfinite(mx) && isfinite(my) && isfinite(radius);
+
+  float nx = 0.f, ny = 0.f, nz = 0.f, q = 0.f, rz = 0.f;
+  if (MODE == MODE_SURFEL) {
+    nx = (V[0] * R02 + V[4] * R12) + V[8] * R22;
+    ny = (V[1] * R02 + V[5] * R12) + V[9] * R22;
+    nz = (V[2] * R02 + V[6] * R12) + V[10] * R22;
+    q = (nx * px + ny * py) + nz * pz;
+    if (p.front_only) {
+      ok = ok && !(q >= 0.0f);
+    } else if (q > 0.0f) {
+      nx = -nx; ny = -ny; nz = -nz; q = -q;
+    }
+    rz = 3.0f * fmaxf(S0, S1);
+  }
+
+  if (ok) {
+    const float msx = mx, msy = my;
+    int xmin = (int)truncf((msx - radius) / (float)TILE);
+    int xmax = (int)truncf((msx + radius + (float)(TILE - 1)) / (float)TILE);
+    int ymin = (int)truncf((msy - radius) / (float)TILE);
+    int ymax = (int)truncf((msy + radius + (float)(TILE - 1)) / (float)TILE);
+    xmin = min(max(xmin, 0), p.gx); xmax = min(max(xmax, 0), p.gx);
+    ymin = min(max(ymin, 0), p.gy); ymax = min(max(ymax, 0), p.gy);
+    const int tiles = (xmax - xmin) * (ymax - ymin);
+    if (tiles > 0) {
+      key = __float_as_uint(pz);
+      rc = make_uint4(0u, (uint32_t)xmin | ((uint32_t)ymin << 16),
+                      (uint32_t)xmax | ((uint32_t)ymax << 16), (uint32_t)tiles);
+      rad = (int)radius;
+    }
+  }
+  depth_key[g] = key;
+  rect[g] = rc;
+  radii[g] = rad;
+  rec[4 * g + 0] = make_float4(mx, my, opacities[g], pz);
+  rec[4 * g + 1] = make_float4(conic_x, conic_y, conic_z, rz);
+  rec[4 * g + 2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], q);
+  rec[4 * g + 3] = make_float4(nx, ny, nz, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void gather_tiles_kernel(int P, const uint32_t* __restrict__ gidx_sorted,
+                                                            const uint4* __restrict__ rect,
+                                                            uint32_t* __restrict__ tiles_sorted) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  tiles_sorted[r] = rect[gidx_sorted[r]].w;
+}
+
+// One thread per Gaussian in depth order: emit its (tile, id) instances.
+__global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
+                                                         const uint32_t* __restrict__ gidx_sorted,
+                                                         const uint32_t* __restrict__ offsets_sorted,
+                                                         uint4* __restrict__ rect,
+                                                         uint32_t* __restrict__ tile_key,
+                                                         uint32_t* __restrict__ gval) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  const uint32_t g = gidx_sorted[r];
+  uint4 rc = rect[g];
+  if (rc.w == 0u) return;
+  uint32_t off = offsets_sorted[r] - rc.w;
+  rc.x = off;
+  rect[g] = rc;
+  const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF, ymax = rc.z >> 16;
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) {
+      tile_key[off] = (uint32_t)(y * gx + x);
+      gval[off] = g;
+      ++off;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const uint32_t* __restrict__ key,
+                                                           uint2* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const uint32_t t = key[i];
+  if (i == 0 || key[i - 1] != t) ranges[t].x = (uint32_t)i;
+  if (i == I - 1 || key[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint4* __restrict__ rect, float* __restrict__ out_color,
+    float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ inst_out) {
+  __shared__ float4 sA[BLOCK];  // mx, my, opacity, pz
+  __shared__ float4 sB[BLOCK];  // conic, rz
+  __shared__ float4 sC[BLOCK];  // rgb, q
+  __shared__ float4 sD[BLOCK];  // normal
+  __shared__ uint32_t sSlot[BLOCK];
+  __shared__ uint32_t sAcc[BLOCK / 64][BLOCK];  // per-wave partial sums (fixed-order reduction)
+
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + (tid & (TILE - 1));
+  const int pix_y = ty * TILE + (tid >> 4);
+  const bool inside = pix_x < p.W && pix_y < p.H;
+  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const size_t HW = (size_t)p.W * p.H;
+  const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+
+  float rx = 0.f, ry = 0.f;
+  if (MODE == MODE_SURFEL) {
+    const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+    const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+    rx = (pixf_x - cxp) / p.fx;
+    ry = (pixf_y - cyp) / p.fy;
+  }
+
+  const uint2 range = ranges[tile];
+  const int todo = (int)(range.y - range.x);
+
+  float T = 1.0f;
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
+  uint32_t contributor = 0, last = 0;
+  bool done = !inside;
+
+  for (int base = 0; base < todo; base += BLOCK) {
+    if (__syncthreads_and(done)) break;
+    const int n = min(BLOCK, todo - base);
+    if (tid < n) {
+      const uint32_t g = point_list[range.x + base + tid];
+      sA[tid] = rec[4 * (size_t)g + 0];
+      sB[tid] = rec[4 * (size_t)g + 1];
+      sC[tid] = rec[4 * (size_t)g + 2];
+      if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
+      const uint4 rc = rect[g];
+      const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
+      sSlot[tid] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+#pragma unroll
+      for (int wv = 0; wv < BLOCK / 64; ++wv) sAcc[wv][tid] = 0u;
+    }
+    __syncthreads();
+
+    for (int j = 0; j < n; ++j) {
+      // wave-uniform exit once every pixel of this wave is saturated
+      if (__all(done)) break;
+      float w = 0.f;
+      bool touched = false;
+      if (!done) {
+        ++contributor;
+        const float4 a = sA[j];
+        const float4 b = sB[j];
+        const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+        const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+        if (power <= 0.0f) {
+          const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+          if (alpha >= ALPHA_MIN) {
+            const float test_T = T * (1.0f - alpha);
+            if (test_T < T_EPS) {
+              done = true;
+            } else {
+              w = alpha * T;
+              const float4 c = sC[j];
+              C0 = fmaf(c.x, w, C0);
+              C1 = fmaf(c.y, w, C1);
+              C2 = fmaf(c.z, w, C2);
+              if (MODE == MODE_SURFEL) {
+                const float4 nn = sD[j];
+                const float den = (nn.x * rx + nn.y * ry) + nn.z;
+                float d = den < -DEN_EPS ? c.w / den : a.w;
+                d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+                N0 = fmaf(nn.x, w, N0);
+                N1 = fmaf(nn.y, w, N1);
+                N2 = fmaf(nn.z, w, N2);
+                D = fmaf(d, w, D);
+              } else {
+                D = fmaf(a.w, w, D);
+                touched = test_T > 0.5f;
+              }
+              T = test_T;
+              last = contributor;
+            }
+          }
+        }
+      }
+      if (MODE == MODE_SURFEL) {
+        if (__any(w != 0.f)) {
+          const float s = wave_reduce_sum_dpp(w);
+          if ((tid & 63) == 63) sAcc[tid >> 6][j] = __float_as_uint(s);
+        }
+      } else {
+        const unsigned long long m = __ballot(touched);
+        if (m != 0ull && (tid & 63) == 0) sAcc[tid >> 6][j] = (uint32_t)__popcll(m);
+      }
+    }
+    __syncthreads();
+    if (tid < n) {
+      if (MODE == MODE_SURFEL) {
+        const float v = ((__uint_as_float(sAcc[0][tid]) + __uint_as_float(sAcc[1][tid])) +
+                         __uint_as_float(sAcc[2][tid])) + __uint_as_float(sAcc[3][tid]);
+        inst_out[sSlot[tid]] = __float_as_uint(v);
+      } else {
+        inst_out[sSlot[tid]] = sAcc[0][tid] + sAcc[1][tid] + sAcc[2][tid] + sAcc[3][tid];
+      }
+    }
+  }
+
+  if (inside) {
+    const float A = 1.0f - T;
+    final_T[pix_id] = T;
+    n_contrib[pix_id] = last;
+    out_color[pix_id] = C0 + T * p.bg[0];
+    out_color[HW + pix_id] = C1 + T * p.bg[1];
+    out_color[2 * HW + pix_id] = C2 + T * p.bg[2];
+    out_alpha[pix_id] = A;
+    if (MODE == MODE_SURFEL) {
+      out_normal[pix_id] = N0;
+      out_normal[HW + pix_id] = N1;
+      out_normal[2 * HW + pix_id] = N2;
+      out_depth[pix_id] = D / fmaxf(A, DEPTH_ALPHA_EPS);
+    } else {
+      out_depth[pix_id] = D;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void per_gaussian_sum_kernel(int P, const uint4* __restrict__ rect,
+                                                                const uint32_t* __restrict__ inst,
+                                                                void* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  const uint4 rc = rect[g];
+  if (MODE == MODE_SURFEL) {
+    float s = 0.f;
+    for (uint32_t k = 0; k < rc.w; ++k) s += __uint_as_float(inst[rc.x + k]);
+    reinterpret_cast<float*>(out)[g] = s;
+  } else {
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < rc.w; ++k) s += inst[rc.x + k];
+    reinterpret_cast<int32_t*>(out)[g] = (int32_t)s;
+  }
+}
+
+static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
+  PINGS_ARG_CHECK(s != nullptr, "null settings");
+  PINGS_ARG_CHECK(s->image_height > 0 && s->image_width > 0, "empty image");
+  PINGS_ARG_CHECK(s->image_height < 65536 * TILE / 16 && s->image_width < 65536, "image too large");
+  PINGS_ARG_CHECK(s->mode == PINGS_RASTER_SURFEL || s->mode == PINGS_RASTER_3DGS, "unknown mode");
+  PINGS_ARG_CHECK(s->viewmatrix && s->projmatrix_raw && s->bg, "null camera pointer");
+  PINGS_ARG_CHECK(s->tanfovx > 0 && s->tanfovy > 0, "non-positive tanfov");
+  kp.P = P;
+  kp.W = s->image_width;
+  kp.H = s->image_height;
+  kp.gx = ceil_div(kp.W, TILE);
+  kp.gy = ceil_div(kp.H, TILE);
+  kp.front_only = s->front_only;
+  kp.fx = (float)((double)kp.W / (2.0 * s->tanfovx));
+  kp.fy = (float)((double)kp.H / (2.0 * s->tanfovy));
+  kp.limx = (float)(1.3 * s->tanfovx);
+  kp.limy = (float)(1.3 * s->tanfovy);
+  kp.scale_mod = (float)s->scale_modifier;
+  kp.view = s->viewmatrix;
+  kp.proj_raw = s->projmatrix_raw;
+  kp.bg = s->bg;
+  kp.prcp = s->prcppoint;
+  return PINGS_OK;
+}
+
+static int tile_bits(int num_tiles) {
+  int b = 1;
+  while ((1 << b) < num_tiles) ++b;
+  return b;
+}
+
+}  // namespace raster
+}  // namespace pings
+
+using namespace pings::raster;
+
+PINGS_API int pings_raster_mark_visible(const float* positions, int N,
+                                        const pings_raster_settings* s, uint8_t* present,
+                                        void* stream) {
+  PINGS_ARG_CHECK(s && s->viewmatrix && s->projmatrix_raw, "null settings / matrices");
+  if (N == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(N > 0 && positions && present, "null pointer");
+  hipLaunchKernelGGL(mark_visible_kernel, dim3(pings::ceil_div(N, 256)), dim3(256), 0,
+                     pings::as_stream(stream), positions, N, s->viewmatrix, s->projmatrix_raw,
+                     present);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API size_t pings_raster_geom_bytes(int P) { return carve_geom(nullptr, P).total; }
+
+PINGS_API size_t pings_raster_binning_bytes(int64_t num_instances, int image_height,
+                                            int image_width) {
+  const int nt = pings::ceil_div(image_width, TILE) * pings::ceil_div(image_height, TILE);
+  return carve_binning(nullptr, num_instances, nt).total;
+}
+
+PINGS_API size_t pings_raster_image_bytes(int image_height, int image_width) {
+  return carve_image(nullptr, image_width, image_height).total;
+}
+
+PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, const float* means3D,
+                                      const float* colors, const float* opacities,
+                                      const float* scales, const float* rotations,
+                                      void* geom_blob, int32_t* radii, int64_t* num_instances,
+                                      void* stream) {
+  KParams kp;
+  if (int e = make_params(s, P, kp)) return e;
+  PINGS_ARG_CHECK(num_instances != nullptr, "null num_instances");
+  *num_instances = 0;
+  if (P == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob && radii,
+                  "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  GeomState gs = carve_geom(geom_blob, P);
+  const dim3 grid(pings::ceil_div(P, 256)), block(256);
+  if (s->mode == PINGS_RASTER_SURFEL)
+    hipLaunchKernelGGL(preprocess_kernel<MODE_SURFEL>, grid, block, 0, st, kp, means3D, colors,
+                       opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<MODE_3DGS>, grid, block, 0, st, kp, means3D, colors,
+                       opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
+  PINGS_LAUNCH_CHECK();
+  size_t tb = gs.temp_bytes;
+  PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
+                                                     gs.gidx, gs.gidx_sorted, P, 0, 32, st));
+  hipLaunchKernelGGL(gather_tiles_kernel, grid, block, 0, st, P, gs.gidx_sorted, gs.rect,
+                     gs.tiles_sorted);
+  PINGS_LAUNCH_CHECK();
+  tb = gs.temp_bytes;
+  PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
+                                                   P, st));
+  uint32_t total = 0;
+  PINGS_HIP_CHECK(hipMemcpyAsync(&total, gs.offsets_sorted + (P - 1), sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+  PINGS_HIP_CHECK(hipStreamSynchronize(st));
+  *num_instances = (int64_t)total;
+  return PINGS_OK;
+}
+
+PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t I,
+                                  void* geom_blob, void* binning_blob, void* image_blob,
+                                  void* inst_scratch, float* out_color, float* out_normal,
+                                  float* out_depth, float* out_alpha, void* per_gaussian,
+                                  void* stream) {
+  KParams kp;
+  if (int e = make_params(s, P, kp)) return e;
+  PINGS_ARG_CHECK(out_color && out_depth && out_alpha && image_blob && binning_blob, "null pointer");
+  PINGS_ARG_CHECK(s->mode == PINGS_RASTER_3DGS || out_normal, "surfel mode needs out_normal");
+  PINGS_ARG_CHECK(I >= 0 && I < (int64_t)0x7FFFFFFF, "instance count out of range");
+  PINGS_ARG_CHECK(P == 0 || (geom_blob && per_gaussian && inst_scratch), "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  const int num_tiles = kp.gx * kp.gy;
+  GeomState gs = carve_geom(geom_blob, P);
+  BinState bs = carve_binning(binning_blob, I, num_tiles);
+  ImageState im = carve_image(image_blob, kp.W, kp.H);
+
+  PINGS_HIP_CHECK(hipMemsetAsync(bs.ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
+  if (I > 0) {
+    hipLaunchKernelGGL(duplicate_kernel, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P, kp.gx,
+                       gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
+    PINGS_LAUNCH_CHECK();
+    size_t tb = bs.temp_bytes;
+    PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key, bs.tile_key_sorted,
+                                                       bs.gval, bs.point_list, (int)I, 0,
+                                                       tile_bits(num_tiles), st));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)),
+                       dim3(256), 0, st, I, bs.tile_key_sorted, bs.ranges);
+    PINGS_LAUNCH_CHECK();
+    PINGS_HIP_CHECK(hipMemsetAsync(inst_scratch, 0, sizeof(uint32_t) * (size_t)I, st));
+  }
+  uint32_t* inst = reinterpret_cast<uint32_t*>(inst_scratch);
+  if (s->mode == PINGS_RASTER_SURFEL)
+    hipLaunchKernelGGL(blend_fwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
+                       bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
+                       out_alpha, im.final_T, im.n_contrib, inst);
+  else
+    hipLaunchKernelGGL(blend_fwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
+                       bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
+                       out_alpha, im.final_T, im.n_contrib, inst);
+  PINGS_LAUNCH_CHECK();
+  if (P > 0) {
+    const dim3 grid(pings::ceil_div(P, 256)), block(256);
+    if (s->mode == PINGS_RASTER_SURFEL)
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<MODE_SURFEL>, grid, block, 0, st, P, gs.rect, inst,
+                         per_gaussian);
+    else
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<MODE_3DGS>, grid, block, 0, st, P, gs.rect, inst,
+                         per_gaussian);
+    PINGS_LAUNCH_CHECK();
+  }
+  return PINGS_OK;
+}
+
+PINGS_API int pings_raster_debug_lists(const void* binning_blob, int64_t I, int image_height,
+                                       int image_width, uint32_t* point_list, uint32_t* ranges_xy,
+                                       void* stream) {
+  PINGS_ARG_CHECK(binning_blob && ranges_xy, "null pointer");
+  const int nt = pings::ceil_div(image_width, TILE) * pings::ceil_div(image_height, TILE);
+  BinState bs = carve_binning(const_cast<void*>(binning_blob), I, nt);
+  hipStream_t st = pings::as_stream(stream);
+  if (I > 0 && point_list)
+    PINGS_HIP_CHECK(hipMemcpyAsync(point_list, bs.point_list, sizeof(uint32_t) * (size_t)I,
+                                   hipMemcpyDeviceToDevice, st));
+  PINGS_HIP_CHECK(hipMemcpyAsync(ranges_xy, bs.ranges, sizeof(uint2) * (size_t)nt,
+                                 hipMemcpyDeviceToDevice, st));
+  return PINGS_OK;
+}
+
+PINGS_API int pings_raster_debug_image(const void* image_blob, int image_height, int image_width,
+                                       float* final_T, uint32_t* n_contrib, void* stream) {
+  PINGS_ARG_CHECK(image_blob && final_T && n_contrib, "null pointer");
+  ImageState im = carve_image(const_cast<void*>(image_blob), image_width, image_height);
+  hipStream_t st = pings::as_stream(stream);
+  const size_t n = (size_t)image_height * image_width;
+  PINGS_HIP_CHECK(hipMemcpyAsync(final_T, im.final_T, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+  PINGS_HIP_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, sizeof(uint32_t) * n,
+                                 hipMemcpyDeviceToDevice, st));
+  return PINGS_OK;
+}

@@ -1,0 +1,233 @@
+"""HIP-backed Gaussian(-surfel) rasteriser behind the reference's extension interface.
+
+Mirrors the two modules the reference imports
+(gaussian_splatting/gaussian_renderer/__init__.py:88-98):
+
+* `diff_gaussian_surfel_rasterization.{GaussianRasterizationSettings, GaussianRasterizer}`
+  — settings fields as constructed at gaussian_renderer/__init__.py:149-166; `__call__`
+  returns `(image, normal, depth, alpha, radii, contributions)` (:318-326).
+* `diff_gaussian_rasterization.{...}` (MonoGS-style 3DGS with pose) — settings at :185-199,
+  `__call__` returns `(image, radii, depth, alpha, n_touched)` (:415-423).
+
+Both expose `markVisible(positions) -> BoolTensor[N]` (:215).  The absent CUDA
+extensions' semantics are restated in oracle/raster_cpu.py; see DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+MODE_SURFEL = 0
+MODE_3DGS = 1
+
+
+class _CSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("mode", C.c_int32), ("front_only", C.c_int32),
+        ("tanfovx", C.c_double), ("tanfovy", C.c_double), ("scale_modifier", C.c_double),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("projmatrix_raw", C.c_void_p), ("prcppoint", C.c_void_p),
+    ]
+
+
+class SurfelRasterizationSettings(NamedTuple):
+    """Field-for-field the record built at gaussian_renderer/__init__.py:149-166."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    patch_bbox: torch.Tensor
+    prcppoint: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    config: torch.Tensor
+
+
+class GS3DRasterizationSettings(NamedTuple):
+    """Field-for-field the record built at gaussian_renderer/__init__.py:185-199."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Prepared:
+    """Device-resident camera tensors + the C settings struct (kept alive together)."""
+
+    def __init__(self, rs, mode: int):
+        self.mode = mode
+        self.H, self.W = int(rs.image_height), int(rs.image_width)
+        self.bg = _f32c(rs.bg).reshape(-1)
+        self.view = _f32c(rs.viewmatrix)
+        self.proj = _f32c(rs.projmatrix)
+        self.proj_raw = _f32c(rs.projmatrix_raw)
+        dev = self.view.device
+        if not self.view.is_cuda:
+            raise _lib.PingsHipError("rasteriser settings must live on the HIP device (no CPU fallback)")
+        front_only = 0
+        self.prcp = None
+        if mode == MODE_SURFEL:
+            self.prcp = _f32c(rs.prcppoint).reshape(-1)
+            cfg = rs.config
+            # config = [surface, normalize_depth, perpix_depth, default, front_only]
+            # (gaussian_renderer/__init__.py:137-142).  The reference always passes 1,1,1,1,f;
+            # only that combination is implemented.  Reading the flags costs one small D2H
+            # copy per settings object, so cache it on the tensor's values lazily.
+            cfg_host = cfg.detach().to("cpu", torch.float32).tolist()
+            if len(cfg_host) != 5 or any(v != 1.0 for v in cfg_host[:4]):
+                raise NotImplementedError(
+                    f"surfel config {cfg_host}: only surface/normalize_depth/perpix_depth/default = 1 "
+                    "(the combination the reference uses) is implemented")
+            front_only = int(cfg_host[4] != 0.0)
+            pb = rs.patch_bbox
+            if pb is not None:
+                pbh = pb.detach().to("cpu", torch.float32).tolist()
+                if pbh != [0.0, 0.0, float(self.H - 1), float(self.W - 1)]:
+                    raise NotImplementedError(
+                        f"patch_bbox {pbh}: only the full-image patch (cameras.py:201-205) is implemented")
+        if int(rs.sh_degree) != 0:
+            raise NotImplementedError("SH evaluation is not part of the PINGS path (colors_precomp only)")
+        self.device = dev
+        self.c = _CSettings(self.H, self.W, mode, front_only, float(rs.tanfovx), float(rs.tanfovy),
+                            float(rs.scale_modifier), self.bg.data_ptr(), self.view.data_ptr(),
+                            self.proj.data_ptr(), self.proj_raw.data_ptr(),
+                            self.prcp.data_ptr() if self.prcp is not None else None)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _declare(L):
+    if getattr(L, "_raster_declared", False):
+        return
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.pings_raster_mark_visible.restype = C.c_int
+    L.pings_raster_mark_visible.argtypes = [vp, i32, C.POINTER(_CSettings), vp, vp]
+    L.pings_raster_geom_bytes.restype = C.c_size_t
+    L.pings_raster_geom_bytes.argtypes = [i32]
+    L.pings_raster_binning_bytes.restype = C.c_size_t
+    L.pings_raster_binning_bytes.argtypes = [i64, i32, i32]
+    L.pings_raster_image_bytes.restype = C.c_size_t
+    L.pings_raster_image_bytes.argtypes = [i32, i32]
+    L.pings_raster_preprocess.restype = C.c_int
+    L.pings_raster_preprocess.argtypes = [C.POINTER(_CSettings), i32, vp, vp, vp, vp, vp, vp, vp,
+                                          C.POINTER(C.c_int64), vp]
+    L.pings_raster_render.restype = C.c_int
+    L.pings_raster_render.argtypes = [C.POINTER(_CSettings), i32, i64, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      vp, vp]
+    if hasattr(L, "pings_raster_backward"):
+        L.pings_raster_backward.restype = C.c_int
+        L.pings_raster_backward.argtypes = [C.POINTER(_CSettings), i32, i64] + [vp] * 25
+    L.pings_raster_debug_lists.restype = C.c_int
+    L.pings_raster_debug_lists.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+    L.pings_raster_debug_image.restype = C.c_int
+    L.pings_raster_debug_image.argtypes = [vp, i32, i32, vp, vp, vp]
+    L._raster_declared = True
+
+
+def _lib_raster():
+    L = _lib.lib()
+    _declare(L)
+    return L
+
+
+def mark_visible(positions: torch.Tensor, prep: _Prepared) -> torch.Tensor:
+    L = _lib_raster()
+    pos = _f32c(positions)
+    N = pos.shape[0]
+    present = torch.empty(N, dtype=torch.uint8, device=pos.device)
+    st = L.pings_raster_mark_visible(_lib.ptr(pos), N, prep.ref(), _lib.ptr(present),
+                                     _lib.stream_ptr(pos.device))
+    _lib.check(st, "pings_raster_mark_visible")
+    return present.bool()
+
+
+class _ForwardState:
+    """Everything the backward pass needs (kept out of save_for_backward on purpose: the
+    3DGS caller divides the returned depth in place, gaussian_renderer/__init__.py:430)."""
+    __slots__ = ("prep", "P", "I", "geom", "binning", "image", "means3D", "colors", "opacities",
+                 "scales", "rotations", "color", "normal", "depth", "alpha")
+
+
+def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
+    L = _lib_raster()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = prep.H, prep.W
+    u8 = dict(dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    stream = _lib.stream_ptr(dev)
+    geom = torch.empty(L.pings_raster_geom_bytes(P), **u8)
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    n_inst = C.c_int64(0)
+    st = L.pings_raster_preprocess(prep.ref(), P, _lib.ptr(means3D), _lib.ptr(colors),
+                                   _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
+                                   _lib.ptr(geom), _lib.ptr(radii), C.byref(n_inst), stream)
+    _lib.check(st, "pings_raster_preprocess")
+    I = int(n_inst.value)
+    binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
+    image = torch.empty(L.pings_raster_image_bytes(H, W), **u8)
+    inst = torch.empty(max(I, 1), dtype=torch.int32, device=dev)
+    color = torch.empty(3, H, W, **f32)
+    depth = torch.empty(1, H, W, **f32)
+    alpha = torch.empty(1, H, W, **f32)
+    if prep.mode == MODE_SURFEL:
+        normal = torch.empty(3, H, W, **f32)
+        per_g = torch.zeros(P, **f32)
+    else:
+        normal = None
+        per_g = torch.zeros(P, dtype=torch.int32, device=dev)
+    st = L.pings_raster_render(prep.ref(), P, I, _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image),
+                               _lib.ptr(inst), _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth),
+                               _lib.ptr(alpha), _lib.ptr(per_g), stream)
+    _lib.check(st, "pings_raster_render")
+    fs = _ForwardState()
+    fs.prep, fs.P, fs.I = prep, P, I
+    fs.geom, fs.binning, fs.image = geom, binning, image
+    fs.means3D, fs.colors, fs.opacities, fs.scales, fs.rotations = means3D, colors, opacities, scales, rotations
+    fs.color, fs.normal, fs.depth, fs.alpha = color, normal, depth, alpha
+    return fs, radii, per_g
+
+
+def debug_lists(fs: _ForwardState):
+    """(point_list[I] int64, ranges[num_tiles,2] int64, final_T[H,W], n_contrib[H,W]) — parity taps for tests."""
+    L = _lib_raster()
+    dev = fs.geom.device
+    H, W = fs.prep.H, fs.prep.W
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = torch.empty(max(fs.I, 1), dtype=torch.int32, device=dev)
+    rg = torch.empty(nt * 2, dtype=torch.int32, device=dev)
+    stream = _lib.stream_ptr(dev)
+    _lib.check(L.pings_raster_debug_lists(_lib.ptr(fs.binning), fs.I, H, W, _lib.ptr(pl), _lib.ptr(rg), stream),
+               "pings_raster_debug_lists")
+    fT = torch.empty(H, W, dtype=torch.float32, device=dev)
+    nc = torch.empty(H, W, dtype=torch.int32, device=dev)
+    _lib.check(L.pings_raster_debug_image(_lib.ptr(fs.image), H, W, _lib.ptr(fT), _lib.ptr(nc), stream),
+               "pings_raster_debug_image")
+    return pl[:fs.I].long(), rg.view(nt, 2).long(), fT, nc

@@ -1,0 +1,76 @@
+"""Seeded synthetic scenes shared by the raster tests (and sized-down bench sanity checks)."""
+import math
+
+import torch
+
+from oracle import raster_cpu as R
+
+
+def random_pose(gen, trans=0.3, rot=0.15):
+    """World->camera transform close to identity (float64)."""
+    w = (torch.rand(3, generator=gen, dtype=torch.float64) - 0.5) * 2 * rot
+    th = w.norm()
+    K = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
+    Rm = torch.eye(3, dtype=torch.float64) + torch.sin(th) / th * K + (1 - torch.cos(th)) / th ** 2 * K @ K
+    T = torch.eye(4, dtype=torch.float64)
+    T[:3, :3] = Rm
+    T[:3, 3] = (torch.rand(3, generator=gen, dtype=torch.float64) - 0.5) * 2 * trans
+    return T
+
+
+def make_scene(P, W, H, seed=0, fx=None, fy=None, cx=None, cy=None, zmin=0.5, zmax=9.0,
+               smin=0.02, smax=0.6, surfel=True, behind_frac=0.1):
+    """Gaussians in (roughly) the camera frustum, float64 tensors on CPU + camera dict."""
+    g = torch.Generator().manual_seed(seed)
+    fx = fx if fx is not None else 0.9 * W
+    fy = fy if fy is not None else 0.9 * W
+    cx = cx if cx is not None else 0.5 * W - 1.7
+    cy = cy if cy is not None else 0.5 * H + 0.9
+    T_cw = random_pose(g)
+    cam = R.look_at_camera(W, H, fx, fy, cx, cy, 0.05, 100.0, T_cw=T_cw, dtype=torch.float64)
+    z = zmin + (zmax - zmin) * torch.rand(P, generator=g, dtype=torch.float64)
+    nb = int(behind_frac * P)
+    if nb:
+        z[:nb] = -z[:nb] * 0.3 + 0.25  # some behind / near the near plane (culled)
+    x = (torch.rand(P, generator=g, dtype=torch.float64) - 0.5) * 1.5 * W / fx * z.abs()
+    y = (torch.rand(P, generator=g, dtype=torch.float64) - 0.5) * 1.5 * H / fy * z.abs()
+    pc = torch.stack([x, y, z], 1)
+    T_wc = torch.linalg.inv(T_cw)
+    means = pc @ T_wc[:3, :3].T + T_wc[:3, 3]
+    ls = math.log(smin) + (math.log(smax) - math.log(smin)) * torch.rand(P, 3, generator=g, dtype=torch.float64)
+    scales = torch.exp(ls)
+    if surfel:
+        scales[:, 2] = 1e-7
+    rot = torch.nn.functional.normalize(torch.randn(P, 4, generator=g, dtype=torch.float64), dim=1)
+    op = 0.05 + 0.95 * torch.rand(P, 1, generator=g, dtype=torch.float64)
+    col = torch.rand(P, 3, generator=g, dtype=torch.float64)
+    bg = torch.tensor([1.0, 0.9, 0.8], dtype=torch.float64)
+    return dict(means=means, scales=scales, rot=rot, op=op, col=col, bg=bg, cam=cam, W=W, H=H)
+
+
+def oracle_settings(sc, dtype, mode="surfel", front_only=True, scale_modifier=1.0):
+    cam = sc["cam"]
+    return R.Settings(sc["H"], sc["W"], cam["tanfovx"], cam["tanfovy"], sc["bg"].to(dtype), scale_modifier,
+                      cam["viewmatrix"].to(dtype), cam["projmatrix"].to(dtype), cam["projmatrix_raw"].to(dtype),
+                      cam["prcppoint"].to(dtype), front_only=front_only, mode=mode)
+
+
+def hip_settings(sc, mode="surfel", front_only=True, scale_modifier=1.0, device="cuda"):
+    from pings_amd import rasterizer as hr
+
+    cam = sc["cam"]
+    f = lambda t: t.to(torch.float32).to(device)
+    H, W = sc["H"], sc["W"]
+    if mode == "surfel":
+        return hr.SurfelRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=f(sc["bg"]),
+            scale_modifier=scale_modifier, viewmatrix=f(cam["viewmatrix"]), projmatrix=f(cam["projmatrix"]),
+            projmatrix_raw=f(cam["projmatrix_raw"]),
+            patch_bbox=torch.tensor([0, 0, H - 1, W - 1], dtype=torch.float32, device=device),
+            prcppoint=f(cam["prcppoint"]), sh_degree=0, campos=f(cam["campos"]), prefiltered=False, debug=False,
+            config=torch.tensor([1, 1, 1, 1, 1 if front_only else 0], dtype=torch.float32, device=device))
+    return hr.GS3DRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=f(sc["bg"]),
+        scale_modifier=scale_modifier, viewmatrix=f(cam["viewmatrix"]), projmatrix=f(cam["projmatrix"]),
+        projmatrix_raw=f(cam["projmatrix_raw"]), sh_degree=0, campos=f(cam["campos"]), prefiltered=False,
+        debug=False)
