@@ -1,0 +1,600 @@
+// Gaussian(-surfel) rasteriser, backward pass, for gfx950.
+//
+//   blend_bwd_kernel      one 256-thread workgroup per 16x16 tile walks the tile's sorted list
+//                         back to front in batches of 64 records staged in LDS.  Each pixel
+//                         re-derives alpha / transmittance, forms the 16 per-(pixel, Gaussian)
+//                         gradient terms of the blend record, and the wave reduces them with a
+//                         transposed DPP reduce-scatter (16 values x 64 lanes -> one 64-B row in
+//                         16 lanes, ~55 VALU ops instead of 96 for 16 separate wave sums).  The
+//                         four waves' rows are summed in LDS in fixed order and stored ONCE per
+//                         (tile, Gaussian) instance as a 64-B row of inst_grads.  No atomics.
+//   gaussian_bwd_kernel   per Gaussian: sums its contiguous run of instance rows, then chains
+//                         through conic / EWA projection / quaternion / scale / camera transform
+//                         to the input gradients and the per-Gaussian pose-tangent terms, which
+//                         are block-reduced to partials (fixed order).
+//   tau_reduce_kernel     final fixed-order reduction of the pose-tangent partials.
+//
+// Gradient definitions are those torch autograd derives from oracle/raster_cpu.py (clamps have
+// zero gradient where active, min(0.99, .) included).
+#include "raster_common.hpp"
+
+namespace pings {
+namespace raster {
+
+struct BParams {
+  int P, W, H, gx, gy;
+  int front_only;
+  float fx, fy, limx, limy, scale_mod;
+  const float* view;
+  const float* proj_raw;
+  const float* bg;
+  const float* prcp;
+};
+
+constexpr int BATCH = 64;
+
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// 4-way lane-dependent select t[(m + K) & 3], m = 2*m1 + m0 (3 v_cndmask).
+template <int K>
+__device__ inline float sel4(const float (&t)[4], bool m0, bool m1) {
+  const float lo = m0 ? t[(1 + K) & 3] : t[K & 3];
+  const float hi = m0 ? t[(3 + K) & 3] : t[(2 + K) & 3];
+  return m1 ? hi : lo;
+}
+
+// Sums v[0..15] over the 64 lanes with a transposed reduce-scatter: two quad_perm exchange
+// steps (16 -> 8 -> 4 values per lane), one rotate step inside each 16-lane row (4 -> 1) and
+// two cross-row adds.  Afterwards lane l of EVERY row holds the wave total of slot
+//   8*(l&1) + 4*((l>>1)&1) + ((l>>2)&3).
+__device__ inline float wave_reduce16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float u[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float send = b0 ? v[k] : v[k + 8];
+    const float keep = b0 ? v[k + 8] : v[k];
+    u[k] = keep + dpp_mov<0xb1>(send);  // quad_perm [1,0,3,2]
+  }
+  float t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float send = b1 ? u[k] : u[k + 4];
+    const float keep = b1 ? u[k + 4] : u[k];
+    t[k] = keep + dpp_mov<0x4e>(send);  // quad_perm [2,3,0,1]
+  }
+  // lanes {c, c+4, c+8, c+12} of a row share the slot base; lane c+4m ends with slot base+m.
+  // row_ror:4k delivers the value of lane (l - 4k) mod 16, whose group index is m-k, so a
+  // sender with group index m' offers t[(m'+k)&3].
+  const bool m0 = lane & 4, m1 = lane & 8;
+  float r = sel4<0>(t, m0, m1);
+  r += dpp_mov<0x124>(sel4<1>(t, m0, m1));  // row_ror:4
+  r += dpp_mov<0x128>(sel4<2>(t, m0, m1));  // row_ror:8
+  r += dpp_mov<0x12c>(sel4<3>(t, m0, m1));  // row_ror:12
+  r += __shfl_xor(r, 16, 64);
+  r += __shfl_xor(r, 32, 64);
+  return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
+    BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint4* __restrict__ rect,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth,
+    const float* __restrict__ dL_dalpha, float* __restrict__ inst_grads) {
+  __shared__ float4 sA[BATCH], sB[BATCH], sC[BATCH], sD[BATCH];
+  __shared__ uint32_t sSlot[BATCH];
+  __shared__ float4 sG[BLOCK / 64][BATCH][4];
+  __shared__ uint32_t sMax;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + (tid & (TILE - 1));
+  const int pix_y = ty * TILE + (tid >> 4);
+  const bool inside = pix_x < p.W && pix_y < p.H;
+  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const size_t HW = (size_t)p.W * p.H;
+  const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+
+  float rx = 0.f, ry = 0.f;
+  if (MODE == MODE_SURFEL) {
+    const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+    const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+    rx = (pixf_x - cxp) / p.fx;
+    ry = (pixf_y - cyp) / p.fy;
+  }
+
+  const uint2 range = ranges[tile];
+  uint32_t last = 0;
+  float T_final = 1.f;
+  float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gD = 0.f, coefT = 0.f;
+  if (inside) {
+    last = n_contrib[pix_id];
+    T_final = final_T[pix_id];
+    if (dL_dcolor) {
+      gC0 = dL_dcolor[pix_id];
+      gC1 = dL_dcolor[HW + pix_id];
+      gC2 = dL_dcolor[2 * HW + pix_id];
+    }
+    float gA = dL_dalpha ? dL_dalpha[pix_id] : 0.f;
+    const float gDo = dL_ddepth ? dL_ddepth[pix_id] : 0.f;
+    if (MODE == MODE_SURFEL) {
+      if (dL_dnormal) {
+        gN0 = dL_dnormal[pix_id];
+        gN1 = dL_dnormal[HW + pix_id];
+        gN2 = dL_dnormal[2 * HW + pix_id];
+      }
+      const float A = 1.0f - T_final;
+      if (A > DEPTH_ALPHA_EPS) {
+        gD = gDo / A;
+        gA -= gDo * out_depth[pix_id] / A;
+      }
+    } else {
+      gD = gDo;
+    }
+    const float bgdot = (p.bg[0] * gC0 + p.bg[1] * gC1) + p.bg[2] * gC2;
+    coefT = (gA - bgdot) * T_final;
+  }
+
+  if (tid == 0) sMax = 0u;
+  __syncthreads();
+  {
+    uint32_t m = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0) atomicMax(&sMax, m);
+  }
+  __syncthreads();
+  const int max_last = (int)sMax;
+
+  float T = T_final;
+  float B0 = 0.f, B1 = 0.f, B2 = 0.f, BN0 = 0.f, BN1 = 0.f, BN2 = 0.f, BD = 0.f;
+
+  const int nbatch = ceil_div(max_last, BATCH);
+  for (int b = nbatch - 1; b >= 0; --b) {
+    const int start = b * BATCH;
+    const int n = min(BATCH, max_last - start);
+    __syncthreads();  // previous batch's LDS fully consumed
+    if (tid < n) {
+      const uint32_t g = point_list[range.x + start + tid];
+      sA[tid] = rec[4 * (size_t)g + 0];
+      sB[tid] = rec[4 * (size_t)g + 1];
+      sC[tid] = rec[4 * (size_t)g + 2];
+      if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
+      const uint4 rc = rect[g];
+      const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
+      sSlot[tid] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+    }
+    {
+      float4* z = &sG[0][0][0];
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < (BLOCK / 64) * BATCH * 4 / BLOCK; ++k) z[tid + k * BLOCK] = zero;
+    }
+    __syncthreads();
+
+    for (int j = n - 1; j >= 0; --j) {
+      const uint32_t idx = (uint32_t)(start + j);
+      bool valid = inside && idx < last;
+      float alpha = 0.f, Gs = 0.f, dx = 0.f, dy = 0.f;
+      float4 a, bq;
+      a = sA[j];
+      bq = sB[j];
+      if (valid) {
+        dx = a.x - pixf_x;
+        dy = a.y - pixf_y;
+        const float power = -0.5f * (bq.x * dx * dx + bq.z * dy * dy) - bq.y * dx * dy;
+        Gs = __expf(power);
+        alpha = fminf(ALPHA_MAX, a.z * Gs);
+        valid = (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      }
+      if (!__any(valid)) continue;
+
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = 0.f;
+      if (valid) {
+        const float one_m = 1.0f - alpha;
+        T = T / one_m;
+        const float w = alpha * T;
+        const float4 c = sC[j];
+        float dLda = ((c.x - B0) * gC0 + (c.y - B1) * gC1) + (c.z - B2) * gC2;
+        B0 = fmaf(alpha, c.x - B0, B0);
+        B1 = fmaf(alpha, c.y - B1, B1);
+        B2 = fmaf(alpha, c.z - B2, B2);
+        v[G_R] = gC0 * w;
+        v[G_G] = gC1 * w;
+        v[G_B] = gC2 * w;
+        if (MODE == MODE_SURFEL) {
+          const float4 nn = sD[j];
+          dLda += ((nn.x - BN0) * gN0 + (nn.y - BN1) * gN1) + (nn.z - BN2) * gN2;
+          BN0 = fmaf(alpha, nn.x - BN0, BN0);
+          BN1 = fmaf(alpha, nn.y - BN1, BN1);
+          BN2 = fmaf(alpha, nn.z - BN2, BN2);
+          float gnx = gN0 * w, gny = gN1 * w, gnz = gN2 * w;
+          // per-pixel depth of this surfel
+          const float den = (nn.x * rx + nn.y * ry) + nn.z;
+          const float zlo = a.w - bq.w, zhi = a.w + bq.w;
+          const bool hit = den < -DEN_EPS;
+          const float d0 = hit ? c.w / den : a.w;
+          const float d = fminf(fmaxf(d0, zlo), zhi);
+          dLda += (d - BD) * gD;
+          BD = fmaf(alpha, d - BD, BD);
+          const float gd = gD * w;
+          if (d0 < zlo) {
+            v[G_ZLO] = gd;
+          } else if (d0 > zhi) {
+            v[G_ZHI] = gd;
+          } else if (hit) {
+            const float inv_den = 1.0f / den;
+            v[G_Q] = gd * inv_den;
+            const float gden = -gd * d0 * inv_den;
+            gnx = fmaf(gden, rx, gnx);
+            gny = fmaf(gden, ry, gny);
+            gnz += gden;
+          } else {
+            v[G_PZ] = gd;
+          }
+          v[G_NX] = gnx;
+          v[G_NY] = gny;
+          v[G_NZ] = gnz;
+        } else {
+          dLda += (a.w - BD) * gD;
+          BD = fmaf(alpha, a.w - BD, BD);
+          v[G_PZ] = gD * w;
+        }
+        dLda = dLda * T + coefT / one_m;
+        // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
+        const float raw = a.z * Gs;
+        if (raw <= ALPHA_MAX) {
+          v[G_OPAC] = Gs * dLda;
+          const float dLp = raw * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
+          const float gdx = dLp * (-bq.x * dx - bq.y * dy);
+          const float gdy = dLp * (-bq.z * dy - bq.y * dx);
+          v[G_MX] = gdx;
+          v[G_MY] = gdy;
+          v[G_CONX] = -0.5f * dx * dx * dLp;
+          v[G_CONY] = -dx * dy * dLp;
+          v[G_CONZ] = -0.5f * dy * dy * dLp;
+        }
+      }
+      const float tot = wave_reduce16(v, lane);
+      if (lane < 16)
+        reinterpret_cast<float*>(&sG[wave][j][0])[((lane & 1) << 3) | ((lane & 2) << 1) | (lane >> 2)] = tot;
+    }
+    __syncthreads();
+    {
+      const int j = tid >> 2, part = tid & 3;
+      if (j < n) {
+        const float4 r0 = sG[0][j][part], r1 = sG[1][j][part], r2 = sG[2][j][part],
+                     r3 = sG[3][j][part];
+        float4 s;
+        s.x = ((r0.x + r1.x) + r2.x) + r3.x;
+        s.y = ((r0.y + r1.y) + r2.y) + r3.y;
+        s.z = ((r0.z + r1.z) + r2.z) + r3.z;
+        s.w = ((r0.w + r1.w) + r2.w) + r3.w;
+        reinterpret_cast<float4*>(inst_grads)[(size_t)sSlot[j] * 4 + part] = s;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- per-Gaussian chain
+template <int MODE>
+__global__ __launch_bounds__(256) void gaussian_bwd_kernel(
+    BParams p, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float4* __restrict__ rec,
+    const uint4* __restrict__ rect, const float* __restrict__ inst_grads,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drotations, float* __restrict__ tau_partials) {
+  __shared__ float sTau[256 / 64][6];
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  if (g < p.P) {
+    const uint4 rc = rect[g];
+    float G[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) G[k] = 0.f;
+    const float4* rows = reinterpret_cast<const float4*>(inst_grads) + (size_t)rc.x * 4;
+    for (uint32_t k = 0; k < rc.w; ++k) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 r = rows[(size_t)k * 4 + q4];
+        G[q4 * 4 + 0] += r.x;
+        G[q4 * 4 + 1] += r.y;
+        G[q4 * 4 + 2] += r.z;
+        G[q4 * 4 + 3] += r.w;
+      }
+    }
+
+    float gm[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gq4[4] = {0.f, 0.f, 0.f, 0.f};
+    float g2d[2] = {0.f, 0.f};
+    if (rc.w > 0) {
+      const float* V = p.view;
+      const float* Pm = p.proj_raw;
+      const float x = means3D[3 * g], y = means3D[3 * g + 1], z = means3D[3 * g + 2];
+      const float px = ((V[0] * x + V[4] * y) + V[8] * z) + V[12];
+      const float py = ((V[1] * x + V[5] * y) + V[9] * z) + V[13];
+      const float pz = ((V[2] * x + V[6] * y) + V[10] * z) + V[14];
+      float gp[3] = {0.f, 0.f, 0.f};
+      // ---- 2-D mean
+      {
+        const float hx = ((Pm[0] * px + Pm[4] * py) + Pm[8] * pz) + Pm[12];
+        const float hy = ((Pm[1] * px + Pm[5] * py) + Pm[9] * pz) + Pm[13];
+        const float hw = ((Pm[3] * px + Pm[7] * py) + Pm[11] * pz) + Pm[15];
+        const float pw = 1.0f / (hw + 1e-7f);
+        const float gndx = 0.5f * (float)p.W * G[G_MX];
+        const float gndy = 0.5f * (float)p.H * G[G_MY];
+        g2d[0] = gndx;
+        g2d[1] = gndy;
+        const float kx = hx * pw * pw, ky = hy * pw * pw;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          gp[i] = gndx * (Pm[4 * i + 0] * pw - kx * Pm[4 * i + 3]) +
+                  gndy * (Pm[4 * i + 1] * pw - ky * Pm[4 * i + 3]);
+      }
+      // ---- covariance
+      const float qr = rotations[4 * g], qx = rotations[4 * g + 1], qy = rotations[4 * g + 2],
+                  qz = rotations[4 * g + 3];
+      float R[3][3];
+      R[0][0] = 1.0f - 2.0f * (qy * qy + qz * qz); R[0][1] = 2.0f * (qx * qy - qr * qz); R[0][2] = 2.0f * (qx * qz + qr * qy);
+      R[1][0] = 2.0f * (qx * qy + qr * qz); R[1][1] = 1.0f - 2.0f * (qx * qx + qz * qz); R[1][2] = 2.0f * (qy * qz - qr * qx);
+      R[2][0] = 2.0f * (qx * qz - qr * qy); R[2][1] = 2.0f * (qy * qz + qr * qx); R[2][2] = 1.0f - 2.0f * (qx * qx + qy * qy);
+      const float S[3] = {p.scale_mod * scales[3 * g], p.scale_mod * scales[3 * g + 1],
+                          p.scale_mod * scales[3 * g + 2]};
+      float RS[3][3], Mc[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) RS[i][k] = R[i][k] * S[k];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          Mc[a][k] = (V[a] * RS[0][k] + V[4 + a] * RS[1][k]) + V[8 + a] * RS[2][k];
+      const float txz = px / pz, tyz = py / pz;
+      const bool clx = (txz < -p.limx) || (txz > p.limx), cly = (tyz < -p.limy) || (tyz > p.limy);
+      const float tx = fminf(p.limx, fmaxf(-p.limx, txz)) * pz;
+      const float ty = fminf(p.limy, fmaxf(-p.limy, tyz)) * pz;
+      const float iz = 1.0f / pz, iz2 = iz * iz;
+      const float J00 = p.fx * iz, J02 = -(p.fx * tx) * iz2, J11 = p.fy * iz, J12 = -(p.fy * ty) * iz2;
+      float T0[3], T1[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        T0[k] = J00 * Mc[0][k] + J02 * Mc[2][k];
+        T1[k] = J11 * Mc[1][k] + J12 * Mc[2][k];
+      }
+      const float ca = ((T0[0] * T0[0] + T0[1] * T0[1]) + T0[2] * T0[2]) + LOWPASS;
+      const float cb = (T0[0] * T1[0] + T0[1] * T1[1]) + T0[2] * T1[2];
+      const float cc = ((T1[0] * T1[0] + T1[1] * T1[1]) + T1[2] * T1[2]) + LOWPASS;
+      const float det = ca * cc - cb * cb;
+      const float id2 = 1.0f / (det * det);
+      const float gcx = G[G_CONX], gcy = G[G_CONY], gcz = G[G_CONZ];
+      const float ga = (-cc * cc * gcx + cb * cc * gcy - cb * cb * gcz) * id2;
+      const float gb = (2.0f * cb * cc * gcx - (ca * cc + cb * cb) * gcy + 2.0f * ca * cb * gcz) * id2;
+      const float gc = (-cb * cb * gcx + ca * cb * gcy - ca * ca * gcz) * id2;
+      float gT0[3], gT1[3], gMc[3][3];
+      float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gT0[k] = 2.0f * ga * T0[k] + gb * T1[k];
+        gT1[k] = 2.0f * gc * T1[k] + gb * T0[k];
+        gJ00 += gT0[k] * Mc[0][k];
+        gJ02 += gT0[k] * Mc[2][k];
+        gJ11 += gT1[k] * Mc[1][k];
+        gJ12 += gT1[k] * Mc[2][k];
+        gMc[0][k] = J00 * gT0[k];
+        gMc[1][k] = J11 * gT1[k];
+        gMc[2][k] = J02 * gT0[k] + J12 * gT1[k];
+      }
+      // J -> camera point
+      gp[2] += -p.fx * iz2 * gJ00 - p.fy * iz2 * gJ11;
+      gp[2] += 2.0f * p.fx * tx * iz2 * iz * gJ02 + 2.0f * p.fy * ty * iz2 * iz * gJ12;
+      const float gtx = -p.fx * iz2 * gJ02, gty = -p.fy * iz2 * gJ12;
+      if (clx) gp[2] += gtx * tx * iz; else gp[0] += gtx;
+      if (cly) gp[2] += gty * ty * iz; else gp[1] += gty;
+      // Mc = Wc RS
+      float gRS[3][3], gWc[3][3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          gRS[b][k] = (V[4 * b + 0] * gMc[0][k] + V[4 * b + 1] * gMc[1][k]) + V[4 * b + 2] * gMc[2][k];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          gWc[a][b] = (gMc[a][0] * RS[b][0] + gMc[a][1] * RS[b][1]) + gMc[a][2] * RS[b][2];
+      float gR[3][3];
+      float gS[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gS[k] += gRS[i][k] * R[i][k];
+          gR[i][k] = gRS[i][k] * S[k];
+        }
+      float gpz_direct = G[G_PZ];
+      if (MODE == MODE_SURFEL) {
+        // normal n = sgn * Wc R[:,2], q = n . p
+        float nx = (V[0] * R[0][2] + V[4] * R[1][2]) + V[8] * R[2][2];
+        float ny = (V[1] * R[0][2] + V[5] * R[1][2]) + V[9] * R[2][2];
+        float nz = (V[2] * R[0][2] + V[6] * R[1][2]) + V[10] * R[2][2];
+        const float q = (nx * px + ny * py) + nz * pz;
+        float sgn = 1.0f;
+        if (!p.front_only && q > 0.0f) sgn = -1.0f;
+        nx *= sgn; ny *= sgn; nz *= sgn;
+        const float gq = G[G_Q];
+        const float gn[3] = {G[G_NX] + gq * px, G[G_NY] + gq * py, G[G_NZ] + gq * pz};
+        gp[0] += gq * nx;
+        gp[1] += gq * ny;
+        gp[2] += gq * nz;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          gR[b][2] += sgn * ((V[4 * b + 0] * gn[0] + V[4 * b + 1] * gn[1]) + V[4 * b + 2] * gn[2]);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gWc[a][b] += sgn * gn[a] * R[b][2];
+        }
+        // depth clamp window zlo = pz - rz, zhi = pz + rz, rz = 3 max(S0, S1)
+        gpz_direct += G[G_ZLO] + G[G_ZHI];
+        const float grz = 3.0f * (G[G_ZHI] - G[G_ZLO]);
+        if (S[0] > S[1]) gS[0] += grz;
+        else if (S[1] > S[0]) gS[1] += grz;
+        else { gS[0] += 0.5f * grz; gS[1] += 0.5f * grz; }
+      }
+      gp[2] += gpz_direct;
+      // quaternion
+      gq4[0] = 2.0f * (-qz * gR[0][1] + qy * gR[0][2] + qz * gR[1][0] - qx * gR[1][2] - qy * gR[2][0] + qx * gR[2][1]);
+      gq4[1] = 2.0f * (qy * gR[0][1] + qz * gR[0][2] + qy * gR[1][0] - 2.0f * qx * gR[1][1] - qr * gR[1][2] + qz * gR[2][0] + qr * gR[2][1] - 2.0f * qx * gR[2][2]);
+      gq4[2] = 2.0f * (-2.0f * qy * gR[0][0] + qx * gR[0][1] + qr * gR[0][2] + qx * gR[1][0] + qz * gR[1][2] - qr * gR[2][0] + qz * gR[2][1] - 2.0f * qy * gR[2][2]);
+      gq4[3] = 2.0f * (-2.0f * qz * gR[0][0] - qr * gR[0][1] + qx * gR[0][2] + qr * gR[1][0] - 2.0f * qz * gR[1][1] + qy * gR[1][2] + qx * gR[2][0] + qy * gR[2][1]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gs[k] = p.scale_mod * gS[k];
+      // world mean: p = Wc m + t
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        gm[b] = (V[4 * b + 0] * gp[0] + V[4 * b + 1] * gp[1]) + V[4 * b + 2] * gp[2];
+      // pose tangent at tau = 0: d rho = gp ; d theta = p x gp + sum_b Wc[:,b] x gWc[:,b]
+      tau[0] = gp[0]; tau[1] = gp[1]; tau[2] = gp[2];
+      float th0 = py * gp[2] - pz * gp[1];
+      float th1 = pz * gp[0] - px * gp[2];
+      float th2 = px * gp[1] - py * gp[0];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float w0 = V[4 * b + 0], w1 = V[4 * b + 1], w2 = V[4 * b + 2];
+        th0 += w1 * gWc[2][b] - w2 * gWc[1][b];
+        th1 += w2 * gWc[0][b] - w0 * gWc[2][b];
+        th2 += w0 * gWc[1][b] - w1 * gWc[0][b];
+      }
+      tau[3] = th0; tau[4] = th1; tau[5] = th2;
+    }
+    dL_dmeans3D[3 * g] = gm[0]; dL_dmeans3D[3 * g + 1] = gm[1]; dL_dmeans3D[3 * g + 2] = gm[2];
+    dL_dmeans2D[3 * g] = g2d[0]; dL_dmeans2D[3 * g + 1] = g2d[1]; dL_dmeans2D[3 * g + 2] = 0.f;
+    dL_dcolors[3 * g] = G[G_R]; dL_dcolors[3 * g + 1] = G[G_G]; dL_dcolors[3 * g + 2] = G[G_B];
+    dL_dopacities[g] = G[G_OPAC];
+    dL_dscales[3 * g] = gs[0]; dL_dscales[3 * g + 1] = gs[1]; dL_dscales[3 * g + 2] = gs[2];
+    dL_drotations[4 * g] = gq4[0]; dL_drotations[4 * g + 1] = gq4[1];
+    dL_drotations[4 * g + 2] = gq4[2]; dL_drotations[4 * g + 3] = gq4[3];
+  }
+
+  // block reduction of the pose-tangent terms (fixed order -> deterministic)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float s = wave_reduce_sum_dpp(tau[k]);
+    if (lane == 63) sTau[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    tau_partials[(size_t)blockIdx.x * 6 + k] = ((sTau[0][k] + sTau[1][k]) + sTau[2][k]) + sTau[3][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void tau_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                          float* __restrict__ dL_dtau) {
+  __shared__ double sRed[256];
+  for (int k = 0; k < 6; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[(size_t)i * 6 + k];
+    sRed[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sRed[threadIdx.x] += sRed[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dL_dtau[k] = (float)sRed[0];
+    __syncthreads();
+  }
+}
+
+}  // namespace raster
+}  // namespace pings
+
+using namespace pings::raster;
+
+PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64_t I,
+                                    const float* means3D, const float* colors,
+                                    const float* opacities, const float* scales,
+                                    const float* rotations, const void* geom_blob,
+                                    const void* binning_blob, const void* image_blob,
+                                    const float* out_color, const float* out_normal,
+                                    const float* out_depth, const float* out_alpha,
+                                    const float* dL_dcolor, const float* dL_dnormal,
+                                    const float* dL_ddepth, const float* dL_dalpha,
+                                    float* inst_grads, float* dL_dmeans3D, float* dL_dmeans2D,
+                                    float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
+                                    float* dL_drotations, float* dL_dtau, void* stream) {
+  PINGS_ARG_CHECK(s != nullptr, "null settings");
+  PINGS_ARG_CHECK(s->mode == PINGS_RASTER_SURFEL || s->mode == PINGS_RASTER_3DGS, "unknown mode");
+  PINGS_ARG_CHECK(dL_dtau != nullptr, "null dL_dtau");
+  hipStream_t st = pings::as_stream(stream);
+  PINGS_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), st));
+  if (P == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob &&
+                      binning_blob && image_blob && out_depth && inst_grads && dL_dmeans3D &&
+                      dL_dmeans2D && dL_dcolors && dL_dopacities && dL_dscales && dL_drotations,
+                  "null pointer");
+  PINGS_ARG_CHECK(I >= 0 && I < (int64_t)0x7FFFFFFF, "instance count out of range");
+  (void)out_color; (void)out_normal; (void)out_alpha;
+  BParams bp;
+  bp.P = P;
+  bp.W = s->image_width;
+  bp.H = s->image_height;
+  bp.gx = pings::ceil_div(bp.W, TILE);
+  bp.gy = pings::ceil_div(bp.H, TILE);
+  bp.front_only = s->front_only;
+  bp.fx = (float)((double)bp.W / (2.0 * s->tanfovx));
+  bp.fy = (float)((double)bp.H / (2.0 * s->tanfovy));
+  bp.limx = (float)(1.3 * s->tanfovx);
+  bp.limy = (float)(1.3 * s->tanfovy);
+  bp.scale_mod = (float)s->scale_modifier;
+  bp.view = s->viewmatrix;
+  bp.proj_raw = s->projmatrix_raw;
+  bp.bg = s->bg;
+  bp.prcp = s->prcppoint;
+  const int num_tiles = bp.gx * bp.gy;
+  GeomState gs = carve_geom(const_cast<void*>(geom_blob), P);
+  BinState bs = carve_binning(const_cast<void*>(binning_blob), I, num_tiles);
+  ImageState im = carve_image(const_cast<void*>(image_blob), bp.W, bp.H);
+
+  if (I > 0) {
+    // rows of instances no pixel reached (early-terminated tiles) must read as zero
+    PINGS_HIP_CHECK(hipMemsetAsync(inst_grads, 0, sizeof(float) * GRAD_ROW * (size_t)I, st));
+    if (s->mode == PINGS_RASTER_SURFEL)
+      hipLaunchKernelGGL(blend_bwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
+                         bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
+                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, inst_grads);
+    else
+      hipLaunchKernelGGL(blend_bwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
+                         bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
+                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, inst_grads);
+    PINGS_LAUNCH_CHECK();
+  }
+  const int nblocks = pings::ceil_div(P, 256);
+  // pose-tangent partials live in the (now consumed) depth-key scratch of the geom blob
+  float* tau_partials = reinterpret_cast<float*>(gs.temp);
+  PINGS_ARG_CHECK((size_t)nblocks * 6 * sizeof(float) <= gs.temp_bytes, "geom scratch too small");
+  if (s->mode == PINGS_RASTER_SURFEL)
+    hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_SURFEL>, dim3(nblocks), dim3(256), 0, st, bp, means3D,
+                       scales, rotations, gs.rec, gs.rect, inst_grads, dL_dmeans3D, dL_dmeans2D,
+                       dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, tau_partials);
+  else
+    hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_3DGS>, dim3(nblocks), dim3(256), 0, st, bp, means3D,
+                       scales, rotations, gs.rec, gs.rect, inst_grads, dL_dmeans3D, dL_dmeans2D,
+                       dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, tau_partials);
+  PINGS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, st, tau_partials, nblocks, dL_dtau);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}

@@ -231,3 +231,115 @@ def debug_lists(fs: _ForwardState):
     _lib.check(L.pings_raster_debug_image(_lib.ptr(fs.image), H, W, _lib.ptr(fT), _lib.ptr(nc), stream),
                "pings_raster_debug_image")
     return pl[:fs.I].long(), rg.view(nt, 2).long(), fT, nc
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """autograd.Function over pings_raster_{preprocess,render,backward}.
+
+    Inputs mirror the extension's `rasterize_gaussians(...)`: means3D, means2D (gradient sink,
+    never read), colors_precomp, opacities, scales, rotations, theta, rho, prepared settings."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, theta, rho, prep):
+        for name, t in (("means3D", means3D), ("colors_precomp", colors), ("opacities", opacities),
+                        ("scales", scales), ("rotations", rotations)):
+            if not t.is_cuda:
+                raise _lib.PingsHipError(f"{name} must be on the HIP device (no CPU fallback)")
+        P = means3D.shape[0]
+        if colors.shape != (P, 3) or scales.shape != (P, 3) or rotations.shape != (P, 4) \
+                or opacities.numel() != P:
+            raise ValueError("rasterizer: inconsistent Gaussian attribute shapes")
+        fs, radii, per_g = _forward(prep, _f32c(means3D), _f32c(colors), _f32c(opacities).reshape(P, 1),
+                                    _f32c(scales), _f32c(rotations))
+        ctx.fs = fs
+        ctx.opac_shape = opacities.shape
+        ctx.has_pose = (theta is not None, rho is not None)
+        ctx.mark_non_differentiable(radii, per_g)
+        # The state object (not save_for_backward) keeps the output tensors: the 3DGS caller
+        # divides the returned depth in place (gaussian_renderer/__init__.py:430), which a saved
+        # tensor's version check would reject; the 3DGS backward never reads that depth, and the
+        # surfel caller does not edit its (already normalised) depth.
+        if prep.mode == MODE_SURFEL:
+            return fs.color, fs.normal, fs.depth, fs.alpha, radii, per_g
+        return fs.color, radii, fs.depth, fs.alpha, per_g
+
+    @staticmethod
+    def backward(ctx, *grads):
+        fs = ctx.fs
+        prep = fs.prep
+        L = _lib_raster()
+        if prep.mode == MODE_SURFEL:
+            g_color, g_normal, g_depth, g_alpha, _, _ = grads
+        else:
+            g_color, _, g_depth, g_alpha, _ = grads
+            g_normal = None
+        dev = fs.means3D.device
+        P, I = fs.P, fs.I
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def gc(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+
+        g_color, g_normal, g_depth, g_alpha = gc(g_color), gc(g_normal), gc(g_depth), gc(g_alpha)
+        inst_grads = torch.empty(max(I, 1) * 16, **f32)
+        d_means3D = torch.empty(P, 3, **f32)
+        d_means2D = torch.empty(P, 3, **f32)
+        d_colors = torch.empty(P, 3, **f32)
+        d_opac = torch.empty(P, 1, **f32)
+        d_scales = torch.empty(P, 3, **f32)
+        d_rot = torch.empty(P, 4, **f32)
+        d_tau = torch.empty(6, **f32)
+        st = L.pings_raster_backward(
+            prep.ref(), P, I, _lib.ptr(fs.means3D), _lib.ptr(fs.colors), _lib.ptr(fs.opacities),
+            _lib.ptr(fs.scales), _lib.ptr(fs.rotations), _lib.ptr(fs.geom), _lib.ptr(fs.binning),
+            _lib.ptr(fs.image), _lib.ptr(fs.color), _lib.ptr(fs.normal), _lib.ptr(fs.depth),
+            _lib.ptr(fs.alpha), _lib.ptr(g_color), _lib.ptr(g_normal), _lib.ptr(g_depth),
+            _lib.ptr(g_alpha), _lib.ptr(inst_grads), _lib.ptr(d_means3D), _lib.ptr(d_means2D),
+            _lib.ptr(d_colors), _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_tau),
+            _lib.stream_ptr(dev))
+        _lib.check(st, "pings_raster_backward")
+        d_theta = d_tau[3:].clone() if ctx.has_pose[0] else None
+        d_rho = d_tau[:3].clone() if ctx.has_pose[1] else None
+        return (d_means3D, d_means2D, d_colors, d_opac.reshape(ctx.opac_shape), d_scales, d_rot,
+                d_theta, d_rho, None)
+
+
+class _RasterizerBase(nn.Module):
+    MODE = MODE_SURFEL
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self._prep: Optional[_Prepared] = None
+
+    def _prepared(self) -> _Prepared:
+        if self._prep is None:
+            self._prep = _Prepared(self.raster_settings, self.MODE)
+        return self._prep
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test of point centres -> BoolTensor[N] (gaussian_renderer/__init__.py:215)."""
+        with torch.no_grad():
+            return mark_visible(positions, self._prepared())
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None, theta=None, rho=None):
+        if shs is not None or colors_precomp is None:
+            raise NotImplementedError("only colors_precomp is supported (the PINGS path never evaluates SH, "
+                                      "gaussian_renderer/__init__.py:110,321)")
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError("only scales + rotations are supported (no cov3D_precomp)")
+        return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations,
+                                         theta, rho, self._prepared())
+
+
+class SurfelGaussianRasterizer(_RasterizerBase):
+    """`diff_gaussian_surfel_rasterization.GaussianRasterizer`: returns
+    (image[3,H,W], normal[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32, contributions[P])."""
+    MODE = MODE_SURFEL
+
+
+class GS3DGaussianRasterizer(_RasterizerBase):
+    """`diff_gaussian_rasterization.GaussianRasterizer` (MonoGS-style, with pose): returns
+    (image[3,H,W], radii[P], depth[1,H,W] un-normalised, alpha[1,H,W], n_touched[P] int32)."""
+    MODE = MODE_3DGS
