@@ -38,6 +38,12 @@ PINGS_API int pings_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). Host string. */
 PINGS_API const char* pings_last_error(void);
 
+/* Per-stage HIP-event timing of everything this library launches (bench.py's roofline
+ * figures).  pings_prof_report synchronises the device and writes "name count total_ms"
+ * lines into a HOST buffer, then clears the record. */
+PINGS_API int pings_prof_enable(int on);
+PINGS_API int pings_prof_report(char* buf, size_t cap);
+
 /* --------------------------------------------------------------- fused SSIM
  * Replaces `fused_ssim.fused_ssim(img1, img2, train=...)`
  * (reference call sites utils/mapper.py:1243,1922,1951; arithmetic of the

@@ -17,6 +17,20 @@ __host__ __device__ constexpr T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Optional per-stage HIP-event timing (off by default; bench.py turns it on to get the
+// per-kernel durations its roofline figures are computed from).
+namespace prof {
+bool enabled();
+void begin(const char* name, hipStream_t st);
+void end(hipStream_t st);
+struct Scope {
+  hipStream_t st;
+  bool on;
+  Scope(const char* name, hipStream_t s) : st(s), on(enabled()) { if (on) begin(name, st); }
+  ~Scope() { if (on) end(st); }
+};
+}  // namespace prof
+
 }  // namespace pings
 
 // Every C-ABI entry point returns 0 on success; HIP failures are turned into

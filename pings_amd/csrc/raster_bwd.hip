@@ -569,6 +569,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   ImageState im = carve_image(const_cast<void*>(image_blob), bp.W, bp.H);
 
   if (I > 0) {
+    pings::prof::Scope ps("blend_bwd", st);
     // rows of instances no pixel reached (early-terminated tiles) must read as zero
     PINGS_HIP_CHECK(hipMemsetAsync(inst_grads, 0, sizeof(float) * GRAD_ROW * (size_t)I, st));
     if (s->mode == PINGS_RASTER_SURFEL)
@@ -585,6 +586,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   // pose-tangent partials live in the (now consumed) depth-key scratch of the geom blob
   float* tau_partials = reinterpret_cast<float*>(gs.temp);
   PINGS_ARG_CHECK((size_t)nblocks * 6 * sizeof(float) <= gs.temp_bytes, "geom scratch too small");
+  pings::prof::Scope ps_g("gaussian_bwd", st);
   if (s->mode == PINGS_RASTER_SURFEL)
     hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_SURFEL>, dim3(nblocks), dim3(256), 0, st, bp, means3D,
                        scales, rotations, gs.rec, gs.rect, inst_grads, dL_dmeans3D, dL_dmeans2D,

@@ -499,22 +499,31 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
   hipStream_t st = pings::as_stream(stream);
   GeomState gs = carve_geom(geom_blob, P);
   const dim3 grid(pings::ceil_div(P, 256)), block(256);
-  if (s->mode == PINGS_RASTER_SURFEL)
-    hipLaunchKernelGGL(preprocess_kernel<MODE_SURFEL>, grid, block, 0, st, kp, means3D, colors,
-                       opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
-  else
-    hipLaunchKernelGGL(preprocess_kernel<MODE_3DGS>, grid, block, 0, st, kp, means3D, colors,
-                       opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
-  PINGS_LAUNCH_CHECK();
+  {
+    pings::prof::Scope ps("preprocess", st);
+    if (s->mode == PINGS_RASTER_SURFEL)
+      hipLaunchKernelGGL(preprocess_kernel<MODE_SURFEL>, grid, block, 0, st, kp, means3D, colors,
+                         opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
+    else
+      hipLaunchKernelGGL(preprocess_kernel<MODE_3DGS>, grid, block, 0, st, kp, means3D, colors,
+                         opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
+    PINGS_LAUNCH_CHECK();
+  }
   size_t tb = gs.temp_bytes;
-  PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
-                                                     gs.gidx, gs.gidx_sorted, P, 0, 32, st));
-  hipLaunchKernelGGL(gather_tiles_kernel, grid, block, 0, st, P, gs.gidx_sorted, gs.rect,
-                     gs.tiles_sorted);
-  PINGS_LAUNCH_CHECK();
-  tb = gs.temp_bytes;
-  PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
-                                                   P, st));
+  {
+    pings::prof::Scope ps("depth_sort", st);
+    PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
+                                                       gs.gidx, gs.gidx_sorted, P, 0, 32, st));
+  }
+  {
+    pings::prof::Scope ps("tile_count_scan", st);
+    hipLaunchKernelGGL(gather_tiles_kernel, grid, block, 0, st, P, gs.gidx_sorted, gs.rect,
+                       gs.tiles_sorted);
+    PINGS_LAUNCH_CHECK();
+    tb = gs.temp_bytes;
+    PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
+                                                     P, st));
+  }
   uint32_t total = 0;
   PINGS_HIP_CHECK(hipMemcpyAsync(&total, gs.offsets_sorted + (P - 1), sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, st));
@@ -542,19 +551,30 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
 
   PINGS_HIP_CHECK(hipMemsetAsync(bs.ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
   if (I > 0) {
-    hipLaunchKernelGGL(duplicate_kernel, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P, kp.gx,
-                       gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
-    PINGS_LAUNCH_CHECK();
-    size_t tb = bs.temp_bytes;
-    PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key, bs.tile_key_sorted,
-                                                       bs.gval, bs.point_list, (int)I, 0,
-                                                       tile_bits(num_tiles), st));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)),
-                       dim3(256), 0, st, I, bs.tile_key_sorted, bs.ranges);
-    PINGS_LAUNCH_CHECK();
-    PINGS_HIP_CHECK(hipMemsetAsync(inst_scratch, 0, sizeof(uint32_t) * (size_t)I, st));
+    {
+      pings::prof::Scope ps("duplicate", st);
+      hipLaunchKernelGGL(duplicate_kernel, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P, kp.gx,
+                         gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
+      PINGS_LAUNCH_CHECK();
+    }
+    {
+      pings::prof::Scope ps("tile_sort", st);
+      size_t tb = bs.temp_bytes;
+      PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key,
+                                                         bs.tile_key_sorted, bs.gval, bs.point_list,
+                                                         (int)I, 0, tile_bits(num_tiles), st));
+    }
+    {
+      pings::prof::Scope ps("tile_ranges", st);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)),
+                         dim3(256), 0, st, I, bs.tile_key_sorted, bs.ranges);
+      PINGS_LAUNCH_CHECK();
+      PINGS_HIP_CHECK(hipMemsetAsync(inst_scratch, 0, sizeof(uint32_t) * (size_t)I, st));
+    }
   }
   uint32_t* inst = reinterpret_cast<uint32_t*>(inst_scratch);
+  {
+  pings::prof::Scope ps_blend("blend_fwd", st);
   if (s->mode == PINGS_RASTER_SURFEL)
     hipLaunchKernelGGL(blend_fwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
                        bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
@@ -564,7 +584,9 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                        bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
                        out_alpha, im.final_T, im.n_contrib, inst);
   PINGS_LAUNCH_CHECK();
+  }
   if (P > 0) {
+    pings::prof::Scope ps("per_gaussian_sum", st);
     const dim3 grid(pings::ceil_div(P, 256)), block(256);
     if (s->mode == PINGS_RASTER_SURFEL)
       hipLaunchKernelGGL(per_gaussian_sum_kernel<MODE_SURFEL>, grid, block, 0, st, P, gs.rect, inst,

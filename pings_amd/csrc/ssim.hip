@@ -233,6 +233,7 @@ PINGS_API int pings_ssim_forward(const float* img1, const float* img2, int plane
                   "train=1 needs the three derivative maps");
   hipStream_t st = pings::as_stream(stream);
   dim3 grid(pings::ceil_div(W, TS), pings::ceil_div(H, TS), planes);
+  pings::prof::Scope ps("ssim_fwd", st);
   if (train) {
     hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(NT), 0, st, img1, img2, H, W, dm_dmu1,
                        dm_dsigma1_sq, dm_dsigma12, partials);
@@ -260,6 +261,7 @@ PINGS_API int pings_ssim_backward(const float* img1, const float* img2, int plan
   hipStream_t st = pings::as_stream(stream);
   dim3 grid(pings::ceil_div(W, TS), pings::ceil_div(H, TS), planes);
   const float inv_count = (float)(1.0 / ((double)planes * H * W));
+  pings::prof::Scope ps("ssim_bwd", st);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(NT), 0, st, img1, img2, H, W, dL_dmean,
                      inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
   PINGS_LAUNCH_CHECK();
