@@ -124,15 +124,19 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
  * Outputs are planar [C,H,W].  out_normal may be NULL in 3DGS mode.  `per_gaussian`
  * is float contributions[P] (surfel: sum of blend weights over pixels) or int32
  * n_touched[P] (3DGS: pixels where the Gaussian is seen with transmittance > 0.5).
- * inst_scratch: device buffer of max(num_instances,1) 4-byte words. */
+ */
 PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t num_instances,
                                   void* geom_blob, void* binning_blob, void* image_blob,
-                                  void* inst_scratch, float* out_color, float* out_normal,
+                                  float* out_color, float* out_normal,
                                   float* out_depth, float* out_alpha, void* per_gaussian,
                                   void* stream);
 
+/* Scratch bytes pings_raster_backward needs (an upper bound in the instance count: the
+ * gradient rows of the instances that actually blended are a data-dependent subset). */
+PINGS_API size_t pings_raster_backward_bytes(int P, int64_t num_instances);
+
 /* Backward of stage 1+2.  dL_d* of the outputs may be NULL (treated as zero).
- * inst_grads: device scratch of max(num_instances,1) * 16 floats.
+ * bwd_blob: device scratch of pings_raster_backward_bytes(P, num_instances) bytes.
  * Gradient outputs are overwritten (not accumulated); dL_dmeans2D[P,3] receives the
  * screen-space positional gradient (xy, z = 0) the reference reads through
  * `viewspace_points`; dL_dtau[6] = [d rho, d theta] for T_cw <- SE3_exp(tau) T_cw
@@ -146,7 +150,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
                                     const float* out_depth, const float* out_alpha,
                                     const float* dL_dcolor, const float* dL_dnormal,
                                     const float* dL_ddepth, const float* dL_dalpha,
-                                    float* inst_grads, float* dL_dmeans3D, float* dL_dmeans2D,
+                                    void* bwd_blob, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
                                     float* dL_drotations, float* dL_dtau, void* stream);
 

@@ -1,21 +1,27 @@
-// Gaussian(-surfel) rasteriser, backward pass, for gfx950.
+// Gaussian(-surfel) rasteriser, backward pass, for gfx950.  No floating-point atomics anywhere.
 //
+//   live scan             cidx = exclusive scan of (inst_w > 0) over the instance slots: only
+//                         instances that blended something in the forward pass get a gradient row.
 //   blend_bwd_kernel      one 256-thread workgroup per 16x16 tile walks the tile's sorted list
-//                         back to front in batches of 64 records staged in LDS.  Each pixel
-//                         re-derives alpha / transmittance, forms the 16 per-(pixel, Gaussian)
-//                         gradient terms of the blend record, and the wave reduces them with a
-//                         transposed DPP reduce-scatter (16 values x 64 lanes -> one 64-B row in
-//                         16 lanes, ~55 VALU ops instead of 96 for 16 separate wave sums).  The
-//                         four waves' rows are summed in LDS in fixed order and stored ONCE per
-//                         (tile, Gaussian) instance as a 64-B row of inst_grads.  No atomics.
-//   gaussian_bwd_kernel   per Gaussian: sums its contiguous run of instance rows, then chains
-//                         through conic / EWA projection / quaternion / scale / camera transform
-//                         to the input gradients and the per-Gaussian pose-tangent terms, which
-//                         are block-reduced to partials (fixed order).
+//                         back to front in batches of 64 records staged in LDS; dead instances are
+//                         skipped by the whole workgroup.  Each pixel re-derives alpha /
+//                         transmittance and forms the 16 per-(pixel, Gaussian) gradient terms of the
+//                         blend record; the wave reduces them with a transposed DPP reduce-scatter
+//                         (16 values x 64 lanes -> one 64-B row in 16 lanes, ~55 VALU ops instead of
+//                         96 for 16 separate wave sums).  The four waves' rows are summed in LDS in
+//                         fixed order and stored ONCE per live instance as a 64-B row; the rows of
+//                         one Gaussian are contiguous (slot order = depth rank order).
+//   row_chunk_sum_kernel  balanced first level of the per-Gaussian sum: one 16-lane group per
+//                         (Gaussian, chunk of <= 64 rows) pair, lane = column, streaming 64-B rows.
+//   gaussian_bwd_kernel   per Gaussian (in depth-rank order): adds its chunk partials, then chains
+//                         through conic / EWA projection / quaternion / scale / camera transform to
+//                         the input gradients and the pose-tangent terms (block-reduced, fixed order).
 //   tau_reduce_kernel     final fixed-order reduction of the pose-tangent partials.
 //
 // Gradient definitions are those torch autograd derives from oracle/raster_cpu.py (clamps have
 // zero gradient where active, min(0.99, .) included).
+#include <hipcub/hipcub.hpp>
+
 #include "raster_common.hpp"
 
 namespace pings {
@@ -32,6 +38,8 @@ struct BParams {
 };
 
 constexpr int BATCH = 64;
+constexpr uint32_t DEAD_ROW = 0xFFFFFFFFu;
+constexpr int CH = 64;  // rows per first-level chunk of the per-Gaussian sum
 
 template <int CTRL>
 __device__ inline float dpp_mov(float v) {
@@ -87,9 +95,10 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha, float* __restrict__ inst_grads) {
+    const float* __restrict__ dL_dalpha, const float* __restrict__ inst_w,
+    const uint32_t* __restrict__ cidx, float* __restrict__ rows) {
   __shared__ float4 sA[BATCH], sB[BATCH], sC[BATCH], sD[BATCH];
-  __shared__ uint32_t sSlot[BATCH];
+  __shared__ uint32_t sRow[BATCH];  // compact gradient-row index, DEAD_ROW for dead instances
   __shared__ float4 sG[BLOCK / 64][BATCH][4];
   __shared__ uint32_t sMax;
 
@@ -171,7 +180,8 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
       if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
       const uint4 rc = rect[g];
       const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
-      sSlot[tid] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+      const uint32_t slot = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+      sRow[tid] = inst_w[slot] > 0.f ? cidx[slot] : DEAD_ROW;
     }
     {
       float4* z = &sG[0][0][0];
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     __syncthreads();
 
     for (int j = n - 1; j >= 0; --j) {
+      if (sRow[j] == DEAD_ROW) continue;  // blended nothing in the forward pass (workgroup-uniform)
       const uint32_t idx = (uint32_t)(start + j);
       bool valid = inside && idx < last;
       float alpha = 0.f, Gs = 0.f, dx = 0.f, dy = 0.f;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     __syncthreads();
     {
       const int j = tid >> 2, part = tid & 3;
-      if (j < n) {
+      if (j < n && sRow[j] != DEAD_ROW) {
         const float4 r0 = sG[0][j][part], r1 = sG[1][j][part], r2 = sG[2][j][part],
                      r3 = sG[3][j][part];
         float4 s;
@@ -281,35 +292,92 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
         s.y = ((r0.y + r1.y) + r2.y) + r3.y;
         s.z = ((r0.z + r1.z) + r2.z) + r3.z;
         s.w = ((r0.w + r1.w) + r2.w) + r3.w;
-        reinterpret_cast<float4*>(inst_grads)[(size_t)sSlot[j] * 4 + part] = s;
+        reinterpret_cast<float4*>(rows)[(size_t)sRow[j] * 4 + part] = s;
       }
     }
   }
+}
+
+// ---------------------------------------------------------------- balanced per-Gaussian row sums
+struct LiveOp {
+  __host__ __device__ uint32_t operator()(const float& w) const { return w > 0.f ? 1u : 0u; }
+};
+
+// per depth rank: compact row range of the Gaussian and its number of <= CH-row chunks
+__global__ __launch_bounds__(256) void row_ranges_kernel(int P, const uint32_t* __restrict__ offsets_sorted,
+                                                          const uint32_t* __restrict__ tiles_sorted,
+                                                          const uint32_t* __restrict__ cidx,
+                                                          uint32_t* __restrict__ cbeg,
+                                                          uint32_t* __restrict__ nch) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > P) return;
+  if (r == P) { nch[P] = 0u; return; }
+  const uint32_t se = offsets_sorted[r], sb = se - tiles_sorted[r];
+  const uint32_t cb = cidx[sb], ce = cidx[se];
+  cbeg[r] = cb;
+  nch[r] = (ce - cb + (uint32_t)CH - 1u) / (uint32_t)CH;
+}
+
+__global__ __launch_bounds__(256) void pair_owner_kernel(int P, const uint32_t* __restrict__ pair_off,
+                                                          uint32_t* __restrict__ pair_owner) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  const uint32_t a = pair_off[r], b = pair_off[r + 1];
+  for (uint32_t q = a; q < b; ++q) pair_owner[q] = (uint32_t)r;
+}
+
+// one 16-lane group per (Gaussian, chunk) pair; lane = column of the 16-float row
+__global__ __launch_bounds__(256) void row_chunk_sum_kernel(int P, const uint32_t* __restrict__ pair_off,
+                                                             const uint32_t* __restrict__ pair_owner,
+                                                             const uint32_t* __restrict__ cbeg,
+                                                             const uint32_t* __restrict__ offsets_sorted,
+                                                             const uint32_t* __restrict__ cidx,
+                                                             const float* __restrict__ rows,
+                                                             float* __restrict__ partials) {
+  const uint32_t q = (uint32_t)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4);
+  const int c = threadIdx.x & 15;
+  if (q >= pair_off[P]) return;
+  const uint32_t r = pair_owner[q];
+  const uint32_t j = q - pair_off[r];
+  const uint32_t row_end = cidx[offsets_sorted[r]];
+  uint32_t row = cbeg[r] + j * (uint32_t)CH;
+  const uint32_t stop = min(row + (uint32_t)CH, row_end);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (; row + 4 <= stop; row += 4) {
+    a0 += rows[(size_t)row * 16 + c];
+    a1 += rows[(size_t)(row + 1) * 16 + c];
+    a2 += rows[(size_t)(row + 2) * 16 + c];
+    a3 += rows[(size_t)(row + 3) * 16 + c];
+  }
+  for (; row < stop; ++row) a0 += rows[(size_t)row * 16 + c];
+  partials[(size_t)q * 16 + c] = (a0 + a1) + (a2 + a3);
 }
 
 // ---------------------------------------------------------------- per-Gaussian chain
 template <int MODE>
 __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
     BParams p, const float* __restrict__ means3D, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float4* __restrict__ rec,
-    const uint4* __restrict__ rect, const float* __restrict__ inst_grads,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
+    const float* __restrict__ rotations, const uint32_t* __restrict__ gidx_sorted,
+    const uint32_t* __restrict__ tiles_sorted, const uint32_t* __restrict__ pair_off,
+    const float* __restrict__ partials, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, float* __restrict__ tau_partials) {
   __shared__ float sTau[256 / 64][6];
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rank = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  if (g < p.P) {
-    const uint4 rc = rect[g];
+  if (rank < p.P) {
+    const int g = (int)gidx_sorted[rank];
+    const uint32_t n_tiles = tiles_sorted[rank];
     float G[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) G[k] = 0.f;
-    const float4* rows = reinterpret_cast<const float4*>(inst_grads) + (size_t)rc.x * 4;
-    for (uint32_t k = 0; k < rc.w; ++k) {
+    const uint32_t qa = pair_off[rank], qb = pair_off[rank + 1];
+    const float4* prow = reinterpret_cast<const float4*>(partials);
+    for (uint32_t k = qa; k < qb; ++k) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 r = rows[(size_t)k * 4 + q4];
+        const float4 r = prow[(size_t)k * 4 + q4];
         G[q4 * 4 + 0] += r.x;
         G[q4 * 4 + 1] += r.y;
         G[q4 * 4 + 2] += r.z;
@@ -319,7 +387,7 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
 
     float gm[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gq4[4] = {0.f, 0.f, 0.f, 0.f};
     float g2d[2] = {0.f, 0.f};
-    if (rc.w > 0) {
+    if (n_tiles > 0 && qb > qa) {
       const float* V = p.view;
       const float* Pm = p.proj_raw;
       const float x = means3D[3 * g], y = means3D[3 * g + 1], z = means3D[3 * g + 2];
@@ -521,7 +589,49 @@ __global__ __launch_bounds__(256) void tau_reduce_kernel(const float* __restrict
 }  // namespace raster
 }  // namespace pings
 
+namespace pings {
+namespace raster {
+
+struct BwdState {
+  uint32_t* cidx;        // [I+2] exclusive scan of live flags over instance slots (cidx[I] = #live)
+  float* rows;           // [I][16] gradient rows of live instances (upper bound; only #live used)
+  uint32_t *cbeg, *nch, *pair_off, *pair_owner;
+  float* partials;       // [NPmax][16]
+  float* tau_partials;   // [ceil(P/256)][6]
+  char* temp;
+  size_t temp_bytes, np_max, total;
+};
+
+static BwdState carve_bwd(void* blob, int P, int64_t I) {
+  Carver c(blob);
+  BwdState b;
+  const size_t n = (size_t)(I > 0 ? I : 1), np = (size_t)(P > 0 ? P : 1);
+  b.np_max = n / CH + np + 1;
+  b.cidx = c.take<uint32_t>(n + 2);
+  b.cbeg = c.take<uint32_t>(np + 1);
+  b.nch = c.take<uint32_t>(np + 1);
+  b.pair_off = c.take<uint32_t>(np + 1);
+  b.pair_owner = c.take<uint32_t>(b.np_max);
+  b.partials = c.take<float>(b.np_max * GRAD_ROW);
+  b.tau_partials = c.take<float>((size_t)ceil_div((int)np, 256) * 6);
+  size_t a = 0, d = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(np + 1));
+  b.temp_bytes = align_up(a > d ? a : d) + 256;
+  b.temp = c.take<char>(b.temp_bytes);
+  b.rows = c.take<float>(n * GRAD_ROW);
+  b.total = c.off;
+  return b;
+}
+
+}  // namespace raster
+}  // namespace pings
+
 using namespace pings::raster;
+
+PINGS_API size_t pings_raster_backward_bytes(int P, int64_t num_instances) {
+  return carve_bwd(nullptr, P, num_instances).total;
+}
 
 PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64_t I,
                                     const float* means3D, const float* colors,
@@ -532,7 +642,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
                                     const float* out_depth, const float* out_alpha,
                                     const float* dL_dcolor, const float* dL_dnormal,
                                     const float* dL_ddepth, const float* dL_dalpha,
-                                    float* inst_grads, float* dL_dmeans3D, float* dL_dmeans2D,
+                                    void* bwd_blob, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
                                     float* dL_drotations, float* dL_dtau, void* stream) {
   PINGS_ARG_CHECK(s != nullptr, "null settings");
@@ -542,10 +652,10 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   PINGS_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), st));
   if (P == 0) return PINGS_OK;
   PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob &&
-                      binning_blob && image_blob && out_depth && inst_grads && dL_dmeans3D &&
+                      binning_blob && image_blob && out_depth && bwd_blob && dL_dmeans3D &&
                       dL_dmeans2D && dL_dcolors && dL_dopacities && dL_dscales && dL_drotations,
                   "null pointer");
-  PINGS_ARG_CHECK(I >= 0 && I < (int64_t)0x7FFFFFFF, "instance count out of range");
+  PINGS_ARG_CHECK(I >= 0 && I < (int64_t)0x7FFFFFF0, "instance count out of range");
   (void)out_color; (void)out_normal; (void)out_alpha;
   BParams bp;
   bp.P = P;
@@ -567,36 +677,65 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   GeomState gs = carve_geom(const_cast<void*>(geom_blob), P);
   BinState bs = carve_binning(const_cast<void*>(binning_blob), I, num_tiles);
   ImageState im = carve_image(const_cast<void*>(image_blob), bp.W, bp.H);
+  BwdState bw = carve_bwd(bwd_blob, P, I);
+  const dim3 gridP(pings::ceil_div(P + 1, 256)), block(256);
 
+  {
+    pings::prof::Scope ps("live_scan", st);
+    if (I > 0) {
+      // inst_w has I+1 entries, the last one zero: cidx[I] = number of live instances
+      hipcub::TransformInputIterator<uint32_t, LiveOp, const float*> flags(bs.inst_w, LiveOp());
+      size_t tb = bw.temp_bytes;
+      PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(bw.temp, tb, flags, bw.cidx, (int)(I + 1), st));
+    } else {
+      PINGS_HIP_CHECK(hipMemsetAsync(bw.cidx, 0, 2 * sizeof(uint32_t), st));
+    }
+    hipLaunchKernelGGL(row_ranges_kernel, gridP, block, 0, st, P, gs.offsets_sorted, gs.tiles_sorted,
+                       bw.cidx, bw.cbeg, bw.nch);
+    PINGS_LAUNCH_CHECK();
+    size_t tb = bw.temp_bytes;
+    PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(bw.temp, tb, bw.nch, bw.pair_off, P + 1, st));
+    hipLaunchKernelGGL(pair_owner_kernel, gridP, block, 0, st, P, bw.pair_off, bw.pair_owner);
+    PINGS_LAUNCH_CHECK();
+  }
   if (I > 0) {
     pings::prof::Scope ps("blend_bwd", st);
-    // rows of instances no pixel reached (early-terminated tiles) must read as zero
-    PINGS_HIP_CHECK(hipMemsetAsync(inst_grads, 0, sizeof(float) * GRAD_ROW * (size_t)I, st));
     if (s->mode == PINGS_RASTER_SURFEL)
       hipLaunchKernelGGL(blend_bwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
                          bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
-                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, inst_grads);
+                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx,
+                         bw.rows);
     else
       hipLaunchKernelGGL(blend_bwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
                          bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
-                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, inst_grads);
+                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx,
+                         bw.rows);
+    PINGS_LAUNCH_CHECK();
+  }
+  {
+    pings::prof::Scope ps("row_chunk_sum", st);
+    const size_t groups = bw.np_max;
+    hipLaunchKernelGGL(row_chunk_sum_kernel, dim3((unsigned)pings::ceil_div<size_t>(groups * 16, 256)),
+                       block, 0, st, P, bw.pair_off, bw.pair_owner, bw.cbeg, gs.offsets_sorted, bw.cidx,
+                       bw.rows, bw.partials);
     PINGS_LAUNCH_CHECK();
   }
   const int nblocks = pings::ceil_div(P, 256);
-  // pose-tangent partials live in the (now consumed) depth-key scratch of the geom blob
-  float* tau_partials = reinterpret_cast<float*>(gs.temp);
-  PINGS_ARG_CHECK((size_t)nblocks * 6 * sizeof(float) <= gs.temp_bytes, "geom scratch too small");
-  pings::prof::Scope ps_g("gaussian_bwd", st);
-  if (s->mode == PINGS_RASTER_SURFEL)
-    hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_SURFEL>, dim3(nblocks), dim3(256), 0, st, bp, means3D,
-                       scales, rotations, gs.rec, gs.rect, inst_grads, dL_dmeans3D, dL_dmeans2D,
-                       dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, tau_partials);
-  else
-    hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_3DGS>, dim3(nblocks), dim3(256), 0, st, bp, means3D,
-                       scales, rotations, gs.rec, gs.rect, inst_grads, dL_dmeans3D, dL_dmeans2D,
-                       dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, tau_partials);
-  PINGS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, st, tau_partials, nblocks, dL_dtau);
-  PINGS_LAUNCH_CHECK();
+  {
+    pings::prof::Scope ps_g("gaussian_bwd", st);
+    if (s->mode == PINGS_RASTER_SURFEL)
+      hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_SURFEL>, dim3(nblocks), block, 0, st, bp, means3D,
+                         scales, rotations, gs.gidx_sorted, gs.tiles_sorted, bw.pair_off, bw.partials,
+                         dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dscales,
+                         dL_drotations, bw.tau_partials);
+    else
+      hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_3DGS>, dim3(nblocks), block, 0, st, bp, means3D,
+                         scales, rotations, gs.gidx_sorted, gs.tiles_sorted, bw.pair_off, bw.partials,
+                         dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dscales,
+                         dL_drotations, bw.tau_partials);
+    PINGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), block, 0, st, bw.tau_partials, nblocks, dL_dtau);
+    PINGS_LAUNCH_CHECK();
+  }
   return PINGS_OK;
 }

@@ -6,7 +6,8 @@
 //                               rect[P]   uint4   : {inst_base, xmin|ymin<<16, xmax|ymax<<16, tiles}
 //                               depth keys / ids (+ sorted copies), tiles-in-depth-order, their scan,
 //                               radix-sort / scan scratch
-//   binning blob (per instance) tile keys / Gaussian ids (+ sorted copies), ranges[num_tiles] uint2, scratch
+//   binning blob (per instance) sorted Gaussian ids, ranges[num_tiles] uint2, per-instance blend-weight sums,
+//                               tile keys / ids before sorting, scratch
 //   image blob   (per pixel)    final_T[HW] float, n_contrib[HW] uint32
 //
 // Instances (Gaussian x touched tile) are created in DEPTH order (the P Gaussians are
@@ -69,6 +70,8 @@ struct GeomState {
 struct BinState {
   uint32_t *tile_key, *tile_key_sorted, *gval, *point_list;
   uint2* ranges;
+  float* inst_w;       // [I+1] per-instance sum of blend weights (0 = instance never blended)
+  uint32_t* inst_cnt;  // [I]   per-instance pixel count with transmittance > 0.5 (3DGS)
   char* temp;
   size_t temp_bytes;
   size_t total;

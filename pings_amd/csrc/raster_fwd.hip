@@ -22,6 +22,8 @@
 // rectangles and the sort order match the fp32 oracle bit for bit.
 #include <hipcub/hipcub.hpp>
 
+#include <type_traits>
+
 #include "raster_common.hpp"
 
 namespace pings {
@@ -70,6 +72,8 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   const size_t n = (size_t)(I > 0 ? I : 1);
   b.point_list = c.take<uint32_t>(n);
   b.ranges = c.take<uint2>((size_t)num_tiles);
+  b.inst_w = c.take<float>(n + 1);
+  b.inst_cnt = c.take<uint32_t>(n);
   b.tile_key = c.take<uint32_t>(n);
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
@@ -233,28 +237,63 @@ __global__ __launch_bounds__(256) void gather_tiles_kernel(int P, const uint32_t
   tiles_sorted[r] = rect[gidx_sorted[r]].w;
 }
 
-// One thread per Gaussian in depth order: emit its (tile, id) instances.
+// Depth ranks are dealt to waves round-robin (lane l of wave w owns rank l*num_waves + w): the
+// nearest Gaussians, which cover the most tiles, sit at neighbouring ranks and would otherwise
+// all land in the first waves.
+__device__ inline int strided_rank(int P) {
+  const int num_waves = (int)(gridDim.x * (blockDim.x >> 6));
+  const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int r = (int)(threadIdx.x & 63) * num_waves + wave;
+  return r < P ? r : -1;
+}
+
+// Emits the (tile id, Gaussian id) instances in depth order.  One lane per Gaussian rank; rects
+// of more than SMALL_RECT tiles are written by the whole wave (coalesced), the rest serially.
+constexpr int SMALL_RECT = 8;
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
                                                          const uint32_t* __restrict__ gidx_sorted,
                                                          const uint32_t* __restrict__ offsets_sorted,
                                                          uint4* __restrict__ rect,
                                                          uint32_t* __restrict__ tile_key,
                                                          uint32_t* __restrict__ gval) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  const uint32_t g = gidx_sorted[r];
-  uint4 rc = rect[g];
-  if (rc.w == 0u) return;
-  uint32_t off = offsets_sorted[r] - rc.w;
-  rc.x = off;
-  rect[g] = rc;
-  const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF, ymax = rc.z >> 16;
-  for (int y = ymin; y < ymax; ++y)
-    for (int x = xmin; x < xmax; ++x) {
-      tile_key[off] = (uint32_t)(y * gx + x);
-      gval[off] = g;
-      ++off;
+  const int r = strided_rank(P);
+  const int lane = threadIdx.x & 63;
+  uint32_t g = 0, off = 0;
+  uint4 rc = make_uint4(0u, 0u, 0u, 0u);
+  if (r >= 0) {
+    g = gidx_sorted[r];
+    rc = rect[g];
+    if (rc.w != 0u) {
+      off = offsets_sorted[r] - rc.w;
+      rc.x = off;
+      rect[g] = rc;
     }
+  }
+  const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF, ymax = rc.z >> 16;
+  if (rc.w != 0u && rc.w <= (uint32_t)SMALL_RECT) {
+    uint32_t o = off;
+    for (int y = ymin; y < ymax; ++y)
+      for (int x = xmin; x < xmax; ++x) {
+        tile_key[o] = (uint32_t)(y * gx + x);
+        gval[o] = g;
+        ++o;
+      }
+  }
+  unsigned long long m = __ballot(rc.w > (uint32_t)SMALL_RECT);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const uint32_t n = (uint32_t)__shfl((int)rc.w, src, 64);
+    const uint32_t o = (uint32_t)__shfl((int)off, src, 64);
+    const uint32_t gg = (uint32_t)__shfl((int)g, src, 64);
+    const int x0 = __shfl(xmin, src, 64), y0 = __shfl(ymin, src, 64);
+    const int wdt = __shfl(xmax, src, 64) - x0;
+    for (uint32_t k = lane; k < n; k += 64) {
+      const int yy = (int)(k / (uint32_t)wdt), xx = (int)(k - (uint32_t)yy * (uint32_t)wdt);
+      tile_key[o + k] = (uint32_t)((y0 + yy) * gx + (x0 + xx));
+      gval[o + k] = gg;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const uint32_t* __restrict__ key,
@@ -271,13 +310,15 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
     KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint4* __restrict__ rect, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ inst_out) {
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_w,
+    uint32_t* __restrict__ inst_cnt) {
   __shared__ float4 sA[BLOCK];  // mx, my, opacity, pz
   __shared__ float4 sB[BLOCK];  // conic, rz
   __shared__ float4 sC[BLOCK];  // rgb, q
   __shared__ float4 sD[BLOCK];  // normal
   __shared__ uint32_t sSlot[BLOCK];
-  __shared__ uint32_t sAcc[BLOCK / 64][BLOCK];  // per-wave partial sums (fixed-order reduction)
+  __shared__ float sAcc[BLOCK / 64][BLOCK];     // per-wave partial sums of blend weights
+  __shared__ uint32_t sCnt[BLOCK / 64][BLOCK];  // per-wave counts (3DGS n_touched)
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -318,7 +359,10 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
       const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
       sSlot[tid] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
 #pragma unroll
-      for (int wv = 0; wv < BLOCK / 64; ++wv) sAcc[wv][tid] = 0u;
+      for (int wv = 0; wv < BLOCK / 64; ++wv) {
+        sAcc[wv][tid] = 0.f;
+        if (MODE == MODE_3DGS) sCnt[wv][tid] = 0u;
+      }
     }
     __syncthreads();
 
@@ -364,24 +408,22 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
           }
         }
       }
-      if (MODE == MODE_SURFEL) {
-        if (__any(w != 0.f)) {
-          const float s = wave_reduce_sum_dpp(w);
-          if ((tid & 63) == 63) sAcc[tid >> 6][j] = __float_as_uint(s);
+      if (__any(w != 0.f)) {
+        const float s = wave_reduce_sum_dpp(w);
+        if ((tid & 63) == 63) sAcc[tid >> 6][j] = s;
+        if (MODE == MODE_3DGS) {
+          const unsigned long long m = __ballot(touched);
+          if ((tid & 63) == 0) sCnt[tid >> 6][j] = (uint32_t)__popcll(m);
         }
-      } else {
-        const unsigned long long m = __ballot(touched);
-        if (m != 0ull && (tid & 63) == 0) sAcc[tid >> 6][j] = (uint32_t)__popcll(m);
       }
     }
     __syncthreads();
     if (tid < n) {
-      if (MODE == MODE_SURFEL) {
-        const float v = ((__uint_as_float(sAcc[0][tid]) + __uint_as_float(sAcc[1][tid])) +
-                         __uint_as_float(sAcc[2][tid])) + __uint_as_float(sAcc[3][tid]);
-        inst_out[sSlot[tid]] = __float_as_uint(v);
-      } else {
-        inst_out[sSlot[tid]] = sAcc[0][tid] + sAcc[1][tid] + sAcc[2][tid] + sAcc[3][tid];
+      const float v = ((sAcc[0][tid] + sAcc[1][tid]) + sAcc[2][tid]) + sAcc[3][tid];
+      if (v != 0.f) {  // untouched slots stay at their memset zero
+        inst_w[sSlot[tid]] = v;
+        if (MODE == MODE_3DGS)
+          inst_cnt[sSlot[tid]] = sCnt[0][tid] + sCnt[1][tid] + sCnt[2][tid] + sCnt[3][tid];
       }
     }
   }
@@ -405,22 +447,55 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void per_gaussian_sum_kernel(int P, const uint4* __restrict__ rect,
-                                                                const uint32_t* __restrict__ inst,
-                                                                void* __restrict__ out) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P) return;
-  const uint4 rc = rect[g];
-  if (MODE == MODE_SURFEL) {
-    float s = 0.f;
-    for (uint32_t k = 0; k < rc.w; ++k) s += __uint_as_float(inst[rc.x + k]);
-    reinterpret_cast<float*>(out)[g] = s;
-  } else {
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < rc.w; ++k) s += inst[rc.x + k];
-    reinterpret_cast<int32_t*>(out)[g] = (int32_t)s;
+__device__ inline uint32_t wave_reduce_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+  return v;
+}
+
+// Per-Gaussian sum of its per-instance values (contiguous run of `tiles` slots).  One lane per
+// depth rank (neighbouring lanes own neighbouring runs); runs longer than SMALL_RUN are summed by
+// the whole wave.  Fixed summation order -> bitwise reproducible.
+constexpr int SMALL_RUN = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void per_gaussian_sum_kernel(
+    int P, const uint32_t* __restrict__ gidx_sorted, const uint32_t* __restrict__ offsets_sorted,
+    const uint32_t* __restrict__ tiles_sorted, const T* __restrict__ inst, T* __restrict__ out) {
+  const int r = strided_rank(P);
+  const int lane = threadIdx.x & 63;
+  uint32_t n = 0, base = 0, g = 0;
+  if (r >= 0) {
+    n = tiles_sorted[r];
+    base = offsets_sorted[r] - n;
+    g = gidx_sorted[r];
   }
+  T sum = (T)0;
+  if (n <= (uint32_t)SMALL_RUN)
+    for (uint32_t k = 0; k < n; ++k) sum += inst[base + k];
+  unsigned long long m = __ballot(n > (uint32_t)SMALL_RUN);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const uint32_t nb = (uint32_t)__shfl((int)n, src, 64);
+    const uint32_t bb = (uint32_t)__shfl((int)base, src, 64);
+    T acc = (T)0, acc1 = (T)0, acc2 = (T)0, acc3 = (T)0;
+    uint32_t k = lane;
+    for (; k + 192 < nb; k += 256) {  // four independent loads in flight
+      acc += inst[bb + k];
+      acc1 += inst[bb + k + 64];
+      acc2 += inst[bb + k + 128];
+      acc3 += inst[bb + k + 192];
+    }
+    for (; k < nb; k += 64) acc += inst[bb + k];
+    acc = (acc + acc1) + (acc2 + acc3);
+    if constexpr (sizeof(T) == 4 && !std::is_integral<T>::value) {
+      acc = wave_sum_to_all(acc);
+    } else {
+      acc = (T)wave_reduce_sum_u32((uint32_t)acc);
+    }
+    if (lane == src) sum = acc;
+  }
+  if (r >= 0) out[g] = sum;
 }
 
 static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
@@ -534,7 +609,7 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
 
 PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t I,
                                   void* geom_blob, void* binning_blob, void* image_blob,
-                                  void* inst_scratch, float* out_color, float* out_normal,
+                                  float* out_color, float* out_normal,
                                   float* out_depth, float* out_alpha, void* per_gaussian,
                                   void* stream) {
   KParams kp;
@@ -542,7 +617,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   PINGS_ARG_CHECK(out_color && out_depth && out_alpha && image_blob && binning_blob, "null pointer");
   PINGS_ARG_CHECK(s->mode == PINGS_RASTER_3DGS || out_normal, "surfel mode needs out_normal");
   PINGS_ARG_CHECK(I >= 0 && I < (int64_t)0x7FFFFFFF, "instance count out of range");
-  PINGS_ARG_CHECK(P == 0 || (geom_blob && per_gaussian && inst_scratch), "null pointer");
+  PINGS_ARG_CHECK(P == 0 || (geom_blob && per_gaussian), "null pointer");
   hipStream_t st = pings::as_stream(stream);
   const int num_tiles = kp.gx * kp.gy;
   GeomState gs = carve_geom(geom_blob, P);
@@ -569,31 +644,37 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
       hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)),
                          dim3(256), 0, st, I, bs.tile_key_sorted, bs.ranges);
       PINGS_LAUNCH_CHECK();
-      PINGS_HIP_CHECK(hipMemsetAsync(inst_scratch, 0, sizeof(uint32_t) * (size_t)I, st));
+      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
+      if (s->mode == PINGS_RASTER_3DGS)
+        PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st));
     }
   }
-  uint32_t* inst = reinterpret_cast<uint32_t*>(inst_scratch);
   {
   pings::prof::Scope ps_blend("blend_fwd", st);
   if (s->mode == PINGS_RASTER_SURFEL)
     hipLaunchKernelGGL(blend_fwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
                        bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
-                       out_alpha, im.final_T, im.n_contrib, inst);
+                       out_alpha, im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt);
   else
     hipLaunchKernelGGL(blend_fwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
                        bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
-                       out_alpha, im.final_T, im.n_contrib, inst);
+                       out_alpha, im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt);
   PINGS_LAUNCH_CHECK();
   }
   if (P > 0) {
     pings::prof::Scope ps("per_gaussian_sum", st);
     const dim3 grid(pings::ceil_div(P, 256)), block(256);
-    if (s->mode == PINGS_RASTER_SURFEL)
-      hipLaunchKernelGGL(per_gaussian_sum_kernel<MODE_SURFEL>, grid, block, 0, st, P, gs.rect, inst,
-                         per_gaussian);
-    else
-      hipLaunchKernelGGL(per_gaussian_sum_kernel<MODE_3DGS>, grid, block, 0, st, P, gs.rect, inst,
-                         per_gaussian);
+    if (I == 0) {
+      PINGS_HIP_CHECK(hipMemsetAsync(per_gaussian, 0, 4 * (size_t)P, st));
+    } else if (s->mode == PINGS_RASTER_SURFEL) {
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<float>, grid, block, 0, st, P, gs.gidx_sorted,
+                         gs.offsets_sorted, gs.tiles_sorted, (const float*)bs.inst_w,
+                         reinterpret_cast<float*>(per_gaussian));
+    } else {
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<uint32_t>, grid, block, 0, st, P, gs.gidx_sorted,
+                         gs.offsets_sorted, gs.tiles_sorted, (const uint32_t*)bs.inst_cnt,
+                         reinterpret_cast<uint32_t*>(per_gaussian));
+    }
     PINGS_LAUNCH_CHECK();
   }
   return PINGS_OK;

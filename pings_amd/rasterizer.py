@@ -139,8 +139,10 @@ def _declare(L):
     L.pings_raster_preprocess.argtypes = [C.POINTER(_CSettings), i32, vp, vp, vp, vp, vp, vp, vp,
                                           C.POINTER(C.c_int64), vp]
     L.pings_raster_render.restype = C.c_int
-    L.pings_raster_render.argtypes = [C.POINTER(_CSettings), i32, i64, vp, vp, vp, vp, vp, vp, vp, vp,
+    L.pings_raster_render.argtypes = [C.POINTER(_CSettings), i32, i64, vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp]
+    L.pings_raster_backward_bytes.restype = C.c_size_t
+    L.pings_raster_backward_bytes.argtypes = [i32, i64]
     if hasattr(L, "pings_raster_backward"):
         L.pings_raster_backward.restype = C.c_int
         L.pings_raster_backward.argtypes = [C.POINTER(_CSettings), i32, i64] + [vp] * 25
@@ -193,7 +195,6 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     I = int(n_inst.value)
     binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
     image = torch.empty(L.pings_raster_image_bytes(H, W), **u8)
-    inst = torch.empty(max(I, 1), dtype=torch.int32, device=dev)
     color = torch.empty(3, H, W, **f32)
     depth = torch.empty(1, H, W, **f32)
     alpha = torch.empty(1, H, W, **f32)
@@ -204,7 +205,7 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
         normal = None
         per_g = torch.zeros(P, dtype=torch.int32, device=dev)
     st = L.pings_raster_render(prep.ref(), P, I, _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image),
-                               _lib.ptr(inst), _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth),
+                               _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth),
                                _lib.ptr(alpha), _lib.ptr(per_g), stream)
     _lib.check(st, "pings_raster_render")
     fs = _ForwardState()
@@ -281,7 +282,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             return None if g is None else g.detach().to(torch.float32).contiguous()
 
         g_color, g_normal, g_depth, g_alpha = gc(g_color), gc(g_normal), gc(g_depth), gc(g_alpha)
-        inst_grads = torch.empty(max(I, 1) * 16, **f32)
+        scratch = torch.empty(L.pings_raster_backward_bytes(P, I), dtype=torch.uint8, device=dev)
         d_means3D = torch.empty(P, 3, **f32)
         d_means2D = torch.empty(P, 3, **f32)
         d_colors = torch.empty(P, 3, **f32)
@@ -294,7 +295,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(fs.scales), _lib.ptr(fs.rotations), _lib.ptr(fs.geom), _lib.ptr(fs.binning),
             _lib.ptr(fs.image), _lib.ptr(fs.color), _lib.ptr(fs.normal), _lib.ptr(fs.depth),
             _lib.ptr(fs.alpha), _lib.ptr(g_color), _lib.ptr(g_normal), _lib.ptr(g_depth),
-            _lib.ptr(g_alpha), _lib.ptr(inst_grads), _lib.ptr(d_means3D), _lib.ptr(d_means2D),
+            _lib.ptr(g_alpha), _lib.ptr(scratch), _lib.ptr(d_means3D), _lib.ptr(d_means2D),
             _lib.ptr(d_colors), _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_tau),
             _lib.stream_ptr(dev))
         _lib.check(st, "pings_raster_backward")
