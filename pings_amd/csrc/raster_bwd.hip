@@ -214,7 +214,8 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
       for (int k = 0; k < 16; ++k) v[k] = 0.f;
       if (valid) {
         const float one_m = 1.0f - alpha;
-        T = T / one_m;
+        const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
+        T = T * inv_one_m;
         const float w = alpha * T;
         const float4 c = sC[j];
         float dLda = ((c.x - B0) * gC0 + (c.y - B1) * gC1) + (c.z - B2) * gC2;
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
           const float den = (nn.x * rx + nn.y * ry) + nn.z;
           const float zlo = a.w - bq.w, zhi = a.w + bq.w;
           const bool hit = den < -DEN_EPS;
-          const float d0 = hit ? c.w / den : a.w;
+          const float inv_den = __builtin_amdgcn_rcpf(den);
+          const float d0 = hit ? c.w * inv_den : a.w;
           const float d = fminf(fmaxf(d0, zlo), zhi);
           dLda += (d - BD) * gD;
           BD = fmaf(alpha, d - BD, BD);
@@ -245,7 +247,6 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
           } else if (d0 > zhi) {
             v[G_ZHI] = gd;
           } else if (hit) {
-            const float inv_den = 1.0f / den;
             v[G_Q] = gd * inv_den;
             const float gden = -gd * d0 * inv_den;
             gnx = fmaf(gden, rx, gnx);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
           BD = fmaf(alpha, a.w - BD, BD);
           v[G_PZ] = gD * w;
         }
-        dLda = dLda * T + coefT / one_m;
+        dLda = fmaf(dLda, T, coefT * inv_one_m);
         // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
         const float raw = a.z * Gs;
         if (raw <= ALPHA_MAX) {

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
               if (MODE == MODE_SURFEL) {
                 const float4 nn = sD[j];
                 const float den = (nn.x * rx + nn.y * ry) + nn.z;
-                float d = den < -DEN_EPS ? c.w / den : a.w;
+                float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
                 d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
                 N0 = fmaf(nn.x, w, N0);
                 N1 = fmaf(nn.y, w, N1);
