@@ -20,7 +20,7 @@ OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: later in-place updates must not leak into the fixture
 
 
 # --------------------------------------------------------------------- G5 ssim
@@ -52,7 +52,134 @@ def make_ssim(R):
         print(f"ssim_{name}: value={val.item():.6f}")
 
 
-GROUPS = {"ssim": make_ssim}
+
+# ---------------------------------------------------------------- G1-G3 SDF query
+def _wavy_points(n, gen, extent=6.0):
+    xy = (torch.rand(n, 2, generator=gen) - 0.5) * 2 * extent
+    z = 2.0 * torch.sin(0.3 * xy[:, 0]) + torch.cos(0.2 * xy[:, 1])
+    return torch.cat([xy, z[:, None]], 1)
+
+
+def build_reference_map(R, cfg_kw, seed=0, n_per_frame=4000, after_pgo=False):
+    """Drives the reference's own NeuralPoints.update / reset_local_map (neural_gaussians.py:214-478)
+    over three synthetic frames and returns (config, neural_points module)."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed)
+    cfg = R.make_config(**cfg_kw)
+    cfg.local_map_radius = 5.0
+    cfg.sorrounding_map_radius = 7.0
+    cfg.color_on = True
+    npm = R.NeuralPoints(cfg)
+    npm.travel_dist = torch.tensor([0.0, 1.0, 2.5], dtype=torch.float32)
+    npm.diff_travel_dist_local = 2.0
+    for ts in range(3):
+        pts = _wavy_points(n_per_frame, gen) + torch.tensor([0.6 * ts, 0.0, 0.0])
+        cols = torch.rand(n_per_frame, 3, generator=gen)
+        npm.update(pts, cols, None, torch.tensor([0.6 * ts, 0.0, 0.5]), torch.eye(3), cur_ts=ts,
+                   is_reliable=(ts != 1))
+    # knock out a few points (pruning flag), give the map non-trivial state
+    npm.valid_gs_mask[::17] = False
+    npm.point_certainties += torch.rand(npm.count(), generator=gen)
+    if after_pgo:
+        npm.after_pgo = True
+        q = torch.nn.functional.normalize(torch.randn(npm.count(), 4, generator=gen), dim=1)
+        npm.point_orientations = q
+    npm.reset_local_map(torch.tensor([1.2, 0.0, 0.5]), torch.eye(3), cur_ts=2)
+    return cfg, npm
+
+
+def _map_state(npm, cfg):
+    tab = npm.buffer_pt_index
+    nz = torch.nonzero(tab >= 0).flatten()
+    st = dict(
+        buffer_size=np.int64(cfg.buffer_size), table_slots=_np(nz), table_vals=_np(tab[nz]),
+        neural_points=_np(npm.neural_points), point_orientations=_np(npm.point_orientations),
+        geo_features=_np(npm.geo_features), color_features=_np(npm.color_features),
+        point_ts_create=_np(npm.point_ts_create), point_ts_update=_np(npm.point_ts_update),
+        point_certainties=_np(npm.point_certainties), free_gs_mask=_np(npm.free_gs_mask),
+        valid_gs_mask=_np(npm.valid_gs_mask), travel_dist=_np(npm.travel_dist), cur_ts=np.int64(npm.cur_ts),
+        diff_travel_dist_local=np.float64(npm.diff_travel_dist_local),
+        local_neural_points=_np(npm.local_neural_points), local_point_orientations=_np(npm.local_point_orientations),
+        local_geo_features=_np(npm.local_geo_features), local_color_features=_np(npm.local_color_features),
+        local_point_certainties=_np(npm.local_point_certainties), local_point_ts_update=_np(npm.local_point_ts_update),
+        local_free_gs_mask=_np(npm.local_free_gs_mask), local_valid_gs_mask=_np(npm.local_valid_gs_mask),
+        global2local=_np(npm.global2local), local_mask=_np(npm.local_mask),
+        neighbor_dx=_np(npm.neighbor_dx), max_valid_dist2=np.float64(npm.max_valid_dist2),
+        resolution=np.float64(npm.resolution), after_pgo=np.bool_(npm.after_pgo),
+        temporal_local_map_on=np.bool_(npm.temporal_local_map_on),
+    )
+    return st
+
+
+SDF_CASES = {
+    # KITTI / IPB-car style (config/run_kitti_gs.yaml:21-27): per-neighbour MLP
+    "gs_f32": dict(voxel_size_m=0.25, search_alpha=0.8, query_nn_k=6, feature_dim=32, color_feature_dim=16,
+                   weighted_first=False, buffer_size=200003, main_loss_type="bce", sigma_sigmoid_m=0.05),
+    # PIN-SLAM style (Replica --gs-off): weighted-first, F = 8
+    "pin_f8": dict(voxel_size_m=0.4, search_alpha=0.5, query_nn_k=6, feature_dim=8, color_feature_dim=8,
+                   weighted_first=True, buffer_size=100003, main_loss_type="bce", sigma_sigmoid_m=0.08),
+    # after a loop closure: neighbour vectors are rotated into each point's frame
+    "pgo_f32": dict(voxel_size_m=0.25, search_alpha=0.8, query_nn_k=8, feature_dim=32, color_feature_dim=16,
+                    weighted_first=False, buffer_size=200003, main_loss_type="bce", sigma_sigmoid_m=0.05),
+}
+
+
+def make_sdf(R):
+    for name, kw in SDF_CASES.items():
+        cfg, npm = build_reference_map(R, kw, seed=len(name), after_pgo=name.startswith("pgo"))
+        gen = torch.Generator().manual_seed(99)
+        dec = R.Decoder(cfg, cfg.feature_dim, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+        with torch.no_grad():
+            for p_ in dec.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=gen) * 0.3)
+        B = 700
+        base = npm.neural_points[torch.randint(0, npm.count(), (B,), generator=gen)]
+        x = base + torch.randn(B, 3, generator=gen) * 0.5 * cfg.voxel_size_m
+        x[:40] += 30.0  # far from everything: zero-neighbour rows
+        out = _map_state(npm, cfg)
+        out.update(x=_np(x), nn_k=np.int64(cfg.query_nn_k), weighted_first=np.bool_(cfg.weighted_first),
+                   sdf_scale=np.float64(dec.sdf_scale))
+        for k_, v_ in dec.state_dict().items():
+            out["dec." + k_] = _np(v_)
+        # G1: radius search, with and without the travel-distance window
+        for tf in (False, True):
+            d2, idx = npm.radius_neighborhood_search(x, time_filtering=tf)
+            out[f"g1_d2_tf{int(tf)}"] = _np(d2)
+            out[f"g1_idx_tf{int(tf)}"] = _np(idx)
+        # G2: query_feature, local + global, with the side effects of training mode
+        cert_before = npm.local_point_certainties.clone()
+        ts_before = npm.local_point_ts_update.clone()
+        qts = torch.full((B,), 2, dtype=torch.int32)
+        geo, colf, w, cnt, cert = npm.query_feature(x, qts, accumulate_stability=True, query_locally=True,
+                                                    query_geo_feature=True, query_color_feature=True)
+        out.update(g2_geo=_np(geo), g2_color=_np(colf), g2_w=_np(w), g2_cnt=_np(cnt), g2_cert=_np(cert),
+                   g2_local_cert_after=_np(npm.local_point_certainties),
+                   g2_local_ts_after=_np(npm.local_point_ts_update))
+        npm.local_point_certainties = cert_before
+        npm.local_point_ts_update = ts_before
+        geo_g, _, w_g, cnt_g, cert_g = npm.query_feature(x, None, accumulate_stability=False, query_locally=False,
+                                                         use_only_valid_points=True)
+        out.update(g2_geo_global=_np(geo_g), g2_w_global=_np(w_g), g2_cnt_global=_np(cnt_g),
+                   g2_cert_global=_np(cert_g))
+        # G3: Mapper.sdf (mapper.py:2273-2289) + analytic gradient (tools.py:409-419) + double backward
+        xg = x.clone().requires_grad_(True)
+        geo, _, w, cnt, _ = npm.query_feature(xg, accumulate_stability=False)
+        s_pred = dec.sdf(geo)
+        if not cfg.weighted_first:
+            s_pred = torch.sum(s_pred * w, dim=1).squeeze(1)  # mapper.py:2279,2285
+        grad_x = R.get_gradient(xg, s_pred)
+        loss = ((grad_x.norm(dim=-1) - 1.0) ** 2).mean() + s_pred.abs().mean()
+        params = [npm.local_geo_features] + list(dec.parameters())
+        gs = torch.autograd.grad(loss, params)
+        out.update(g3_sdf=_np(s_pred), g3_grad_x=_np(grad_x), g3_loss=_np(loss), g3_dfeat=_np(gs[0]))
+        for (k_, _), g_ in zip(dec.named_parameters(), gs[1:]):
+            out["g3_d." + k_] = _np(g_)
+        np.savez_compressed(OUT / f"sdf_{name}.npz", **out)
+        print(f"sdf_{name}: Np={npm.count()} local={npm.local_count()} K={npm.neighbor_K} "
+              f"mean nn={cnt.float().mean():.1f} zero-rows={(cnt == 0).sum().item()} loss={loss.item():.5f}")
+
+
+GROUPS = {"ssim": make_ssim, "sdf": make_sdf}
 
 
 def main(argv):
