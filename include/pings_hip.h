@@ -162,4 +162,64 @@ PINGS_API int pings_raster_debug_lists(const void* binning_blob, int64_t num_ins
 PINGS_API int pings_raster_debug_image(const void* image_blob, int image_height, int image_width,
                                        float* final_T, uint32_t* n_contrib, void* stream);
 
+
+/* -------------------------------------------- neural-point kNN + SDF decode
+ * Replaces, for the query path, `NeuralPoints.radius_neighborhood_search`
+ * (model/neural_gaussians.py:1061-1115), the search / filter / top-k part of
+ * `NeuralPoints.query_feature` (:506-569) and, fused, the whole of `Mapper.sdf`
+ * (utils/mapper.py:2273-2289 = query_feature + Decoder.sdf (model/decoder.py:62-104)
+ * + inverse-distance weighting) with its analytic gradient (utils/tools.py:409-419).
+ * All index tensors keep the reference's dtypes (int64 table / indices, int32
+ * timestamps, uint8 bool masks) so the reference's own tensors are passed as they are.
+ */
+typedef struct pings_knn_map {
+  const int64_t* table;          /* buffer_pt_index[buffer_size], -1 = empty (neural_gaussians.py:86-88) */
+  int64_t buffer_size;
+  const float* neural_points;    /* [Np,3] global positions                                   */
+  const int32_t* point_ts_create;/* [Np]   (travel-distance window; may be NULL if !time_filtering) */
+  const float* travel_dist;      /* [T]                                                        */
+  int32_t cur_ts;
+  int32_t time_filtering;        /* temporal_local_map_on && query_locally (:535)              */
+  float diff_travel_dist_local;
+  const uint8_t* free_mask;      /* [Np] free_gs_mask;  used iff use_free_mask  (:544-546)     */
+  const uint8_t* valid_mask;     /* [Np] valid_gs_mask; used iff use_valid_mask (:548-550)     */
+  int32_t use_free_mask, use_valid_mask;
+  const int64_t* global2local;   /* [Np+1] or NULL for a global query (:553-554)               */
+  const int32_t* neighbor_dx;    /* [K,3] cell offsets (:1030-1043)                            */
+  int32_t K;
+  int32_t nn_k;                  /* config.query_nn_k (<= 16)                                  */
+  float resolution;              /* voxel size                                                 */
+  float max_valid_dist2;         /* 3*((n+1)*res)^2 (:1058)                                    */
+} pings_knn_map;
+
+/* idx[B,nn_k] (int64, -1 = none; local indices iff global2local != NULL), d2[B,nn_k]
+ * (9e3 where idx = -1, :562), nn_counts[B] (int64: valid candidates over all K cells, :557).
+ * Neighbours are ordered by squared distance, ties by candidate cell order.
+ * global_idx[B,nn_k] (optional, may be NULL): the neighbours' indices before the
+ * global2local mapping, i.e. the rows of `neural_points` the distances were measured to. */
+PINGS_API int pings_knn_search(const pings_knn_map* m, const float* queries, int64_t B,
+                               int64_t* idx, float* d2, int64_t* nn_counts, int64_t* global_idx,
+                               void* stream);
+
+typedef struct pings_sdf_decoder {
+  const float* W1;   /* [hidden, F+3] layers.0.weight (decoder.py:49) */
+  const float* b1;   /* [hidden]                                      */
+  const float* W2;   /* [1, hidden]   lout.weight                      */
+  const float* b2;   /* [1]                                            */
+  int32_t hidden;    /* <= 64                                          */
+  int32_t feat_dim;  /* F (<= 61)                                      */
+  float sdf_scale;   /* decoder.py:55-57                               */
+  int32_t weighted_first; /* config.weighted_first (neural_gaussians.py:701) */
+} pings_sdf_decoder;
+
+/* Fused inference query: sdf[B]; optional (may be NULL) grad_x[B,3] = d sdf / d query,
+ * nn_counts[B] (int64), certainty[B].  `features` is [rows, F] (local or global table matching
+ * the index space of the search), `points`/`orientations`/`certainties` likewise
+ * ([rows,3], [rows,4] wxyz or NULL unless after_pgo, [rows] or NULL). No side effects. */
+PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder* dec,
+                                const float* features, const float* points,
+                                const float* orientations, const float* certainties,
+                                int32_t after_pgo, const float* queries, int64_t B, float* sdf,
+                                float* grad_x, int64_t* nn_counts, float* certainty, void* stream);
+
 #endif /* PINGS_HIP_H_ */
