@@ -97,6 +97,159 @@ def cpu_baseline_raster(P_sample=4000, W=240, H=136, threads=None):
                       f"{W}x{H} ({dt:.1f} s of CPU work; host has {os.cpu_count()} logical cores)"}
 
 
+# --------------------------------------------------------------------------- SDF (Metric 2)
+SDF_PRIMES = (73856093, 19349669, 83492791)
+
+
+def sdf_synth_map(n_points, device, voxel=0.25, search_alpha=0.8, nn_k=6, feat_dim=32, hidden=64,
+                  buffer_size=int(1e8), seed=42):
+    """SURVEY.md §8d Metric 2 map, built on the device: neural points on the wavy sheet
+    z = 2 sin(0.3x) + cos(0.2y), one per 0.25 m voxel, inserted into the 1e8-slot int64 hash table
+    with the reference's rule (later insert wins, model/neural_gaussians.py:243-247,299-308)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    side = (n_points * 1.15) ** 0.5 * voxel
+    xy = (torch.rand(int(n_points * 4), 2, generator=g, device=device) - 0.5) * side
+    z = 2.0 * torch.sin(0.3 * xy[:, 0]) + torch.cos(0.2 * xy[:, 1])
+    pts = torch.cat([xy, z[:, None]], 1)
+    cells = torch.floor(pts / voxel).to(torch.int64)
+    key = (cells[:, 0] + 2 ** 20) * 2 ** 42 + (cells[:, 1] + 2 ** 20) * 2 ** 21 + (cells[:, 2] + 2 ** 20)
+    uniq, inv = torch.unique(key, return_inverse=True)
+    first = torch.full((uniq.shape[0],), key.shape[0], dtype=torch.int64, device=device)
+    first.scatter_reduce_(0, inv, torch.arange(key.shape[0], device=device), reduce="amin")
+    first = torch.sort(first).values[:n_points]
+    pts, cells = pts[first].contiguous(), cells[first]
+    n = pts.shape[0]
+    primes = torch.tensor(SDF_PRIMES, dtype=torch.int64, device=device)
+    h = torch.fmod((cells * primes).sum(-1), buffer_size)
+    slots = torch.where(h < 0, h + buffer_size, h)
+    table = torch.full((buffer_size,), -1, dtype=torch.int64, device=device)
+    table.scatter_reduce_(0, slots, torch.arange(n, device=device), reduce="amax")
+    dx = torch.arange(-2, 3, dtype=torch.int64, device=device)
+    dxyz = torch.stack(torch.meshgrid(dx, dx, dx, indexing="ij"), -1).reshape(-1, 3)
+    dxyz = dxyz[(dxyz ** 2).sum(-1) < (2 + search_alpha) ** 2]
+    feats = torch.cat([0.05 * torch.randn(n, feat_dim, generator=g, device=device),
+                       torch.zeros(1, feat_dim, device=device)])
+    in_dim = feat_dim + 3
+    dec = {"layers.0.weight": torch.randn(hidden, in_dim, generator=g, device=device) / in_dim ** 0.5,
+           "layers.0.bias": 0.1 * torch.randn(hidden, generator=g, device=device),
+           "lout.weight": torch.randn(1, hidden, generator=g, device=device) / hidden ** 0.5,
+           "lout.bias": 0.1 * torch.randn(1, generator=g, device=device)}
+    from types import SimpleNamespace as NS
+
+    npm = NS(buffer_pt_index=table, neural_points=pts, point_orientations=None, geo_features=feats,
+             color_features=None, point_ts_create=torch.zeros(n, dtype=torch.int32, device=device),
+             point_certainties=torch.zeros(n, device=device),
+             free_gs_mask=torch.zeros(n, dtype=torch.bool, device=device),
+             valid_gs_mask=torch.ones(n, dtype=torch.bool, device=device),
+             travel_dist=torch.zeros(1, device=device), cur_ts=0, diff_travel_dist_local=1e9,
+             local_neural_points=pts, local_geo_features=feats, local_color_features=None,
+             local_point_certainties=torch.zeros(n, device=device),
+             local_point_ts_update=torch.zeros(n, dtype=torch.int32, device=device),
+             local_point_orientations=torch.tensor([1.0, 0, 0, 0], device=device).repeat(n, 1),
+             global2local=torch.cat([torch.arange(n, device=device), torch.tensor([-1], device=device)]),
+             neighbor_dx=dxyz, max_valid_dist2=3 * ((2 + 1) * voxel) ** 2, resolution=voxel, after_pgo=False,
+             temporal_local_map_on=False, nn_k=nn_k, weighted_first=False, geo_feature_dim=feat_dim,
+             color_feature_dim=0, dtype=torch.float32,
+             config=NS(query_nn_k=nn_k, weighted_first=False, layer_norm_on=False))
+    npm.point_orientations = npm.local_point_orientations
+    decoder = NS(layers=[NS(weight=dec["layers.0.weight"], bias=dec["layers.0.bias"])],
+                 lout=NS(weight=dec["lout.weight"], bias=dec["lout.bias"]), sdf_scale=0.55 * 0.05,
+                 use_leaky_relu=False)
+    return npm, decoder
+
+
+def sdf_queries(npm, B, device, seed=7):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sel = torch.randint(0, npm.neural_points.shape[0], (B,), generator=g, device=device)
+    return (npm.neural_points[sel] + torch.randn(B, 3, generator=g, device=device) * (0.5 * npm.resolution)).contiguous()
+
+
+def bench_sdf(dev, steps, warmup, n_points=1_000_000, batches=(16384, 131072)):
+    """Metric 2: Msamples/s of the fused query (search + gather + IDW + MLP) and of the training-style
+    fwd+bwd (HIP search + autograd through gather/IDW/MLP to features and MLP weights)."""
+    from pings_amd import neural_points as hnp
+
+    npm, dec = sdf_synth_map(n_points, dev)
+    out = {"neural_points": int(npm.neural_points.shape[0]), "voxel_m": 0.25, "K": int(npm.neighbor_dx.shape[0]),
+           "nn_k": 6, "feature_dim": 32, "hidden": 64, "buffer_size": int(1e8)}
+    for B in batches:
+        x = sdf_queries(npm, B, dev)
+        for _ in range(warmup):
+            hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sdf, _, cnt, _ = hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
+        torch.cuda.synchronize()
+        t_f = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hnp.sdf_fused(npm, dec, x, need_grad=True, use_only_measured_points=False)
+        torch.cuda.synchronize()
+        t_g = (time.perf_counter() - t0) / steps
+        # training-style fwd+bwd
+        feats = npm.local_geo_features.detach().clone().requires_grad_(True)
+        npm.local_geo_features = feats
+        W = [dec.layers[0].weight.detach().clone().requires_grad_(True), dec.layers[0].bias.detach().clone().requires_grad_(True),
+             dec.lout.weight.detach().clone().requires_grad_(True), dec.lout.bias.detach().clone().requires_grad_(True)]
+
+        def train_step():
+            geo, _, w, c, _ = hnp.query_feature(npm, x, accumulate_stability=False, use_only_measured_points=False)
+            h = torch.relu(torch.nn.functional.linear(geo, W[0], W[1]))
+            s = (torch.nn.functional.linear(h, W[2], W[3]) * dec.sdf_scale * w).sum(1).squeeze(1)
+            loss = s.abs().mean()
+            return torch.autograd.grad(loss, [feats] + W)
+
+        for _ in range(warmup):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train_step()
+        torch.cuda.synchronize()
+        t_t = (time.perf_counter() - t0) / steps
+        out[f"B{B}"] = {"fwd_fused_Msamples_s": round(B / t_f / 1e6, 2),
+                        "fwd_with_grad_x_Msamples_s": round(B / t_g / 1e6, 2),
+                        "fwd_bwd_autograd_Msamples_s": round(B / t_t / 1e6, 2),
+                        "fwd_ms": round(t_f * 1e3, 4),
+                        "hbm_alg_GBs_fwd": round(2428 * B / t_f / 1e9, 1),
+                        "hbm_sector_GBs_fwd": round(10400 * B / t_f / 1e9, 1),
+                        "mean_nn_count": round(cnt.float().mean().item(), 2)}
+        npm.local_geo_features = npm.geo_features
+    return out, npm, dec
+
+
+def cpu_baseline_sdf(npm, dec, B=16384, reps=3):
+    """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores,
+    same map and queries as the GPU run (tensors copied to the host)."""
+    from oracle import sdf_cpu
+
+    c = lambda t: t.detach().cpu().numpy()
+    st = dict(buffer_size=int(npm.buffer_pt_index.shape[0]), buffer_pt_index=c(npm.buffer_pt_index),
+              neural_points=c(npm.neural_points), point_orientations=c(npm.point_orientations),
+              geo_features=c(npm.geo_features), point_ts_create=c(npm.point_ts_create),
+              point_ts_update=c(npm.point_ts_create), point_certainties=c(npm.point_certainties),
+              free_gs_mask=c(npm.free_gs_mask), valid_gs_mask=c(npm.valid_gs_mask), travel_dist=c(npm.travel_dist),
+              cur_ts=0, diff_travel_dist_local=1e9, local_neural_points=c(npm.neural_points),
+              local_point_orientations=c(npm.point_orientations), local_geo_features=c(npm.geo_features),
+              local_point_certainties=c(npm.point_certainties), local_point_ts_update=c(npm.point_ts_create),
+              global2local=c(npm.global2local), neighbor_dx=c(npm.neighbor_dx), max_valid_dist2=npm.max_valid_dist2,
+              resolution=npm.resolution, after_pgo=False, temporal_local_map_on=False, nn_k=6, weighted_first=False)
+    cm = sdf_cpu.NeuralPointMap(st)
+    mlp = sdf_cpu.MLP(dec.layers[0].weight.cpu(), dec.layers[0].bias.cpu(), dec.lout.weight.cpu(), dec.lout.bias.cpu(),
+                      dec.sdf_scale)
+    x = sdf_queries(npm, B, npm.neural_points.device).cpu()
+    with torch.no_grad():
+        sdf_cpu.mapper_sdf(cm, mlp, x)  # warm-up
+        t0 = time.time()
+        for _ in range(reps):
+            s, _ = sdf_cpu.mapper_sdf(cm, mlp, x)
+        dt = (time.time() - t0) / reps
+    return {"value": round(B / dt / 1e6, 4), "unit": "Msamples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/sdf_cpu.py (reference torch op sequence) forward, B={B} queries x {reps} reps on the same "
+                      f"1M-point map ({dt * reps:.1f} s of CPU work; host has {os.cpu_count()} logical cores)"}, s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +260,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mode", default="surfel", choices=["surfel", "3dgs"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sdf", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +393,15 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline_raster()
+        sdf = None
+        if not args.no_sdf:
+            for p_ in params:
+                p_.grad = None
+            del fs
+            torch.cuda.empty_cache()
+            sdf, npm, dec = bench_sdf(dev, max(args.steps, 5), max(args.warmup, 2))
+            if not args.no_cpu_baseline:
+                sdf["cpu_baseline"], _ = cpu_baseline_sdf(npm, dec)
         line = {
             "metric": "raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -249,7 +412,7 @@ def main():
                        "gaussians": P, "width": W, "height": H, "instances": int(I),
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
