@@ -347,9 +347,12 @@ def main():
         step()
     sync()
     L.pings_prof_enable(1)
+    host_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        host_ms.append((time.perf_counter() - ts) * 1e3)  # host-side issue time only (no sync)
     sync()
     elapsed = time.perf_counter() - t0
     L.pings_prof_enable(0)
@@ -412,6 +415,8 @@ def main():
                        "gaussians": P, "width": W, "height": H, "instances": int(I),
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
+            "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
+                                       "max": round(max(host_ms), 3)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf,
         }
         print(json.dumps(line), flush=True)

@@ -179,7 +179,78 @@ def make_sdf(R):
               f"mean nn={cnt.float().mean():.1f} zero-rows={(cnt == 0).sum().item()} loss={loss.item():.5f}")
 
 
-GROUPS = {"ssim": make_ssim, "sdf": make_sdf}
+
+# ---------------------------------------------------------------- G4 spawn_gaussians
+SPAWN_CASES = {
+    # name: (gs_type, learn_color_residual, view_concat_on, dist_concat_on)
+    "surfel_res_view": ("gaussian_surfel", True, True, False),    # config/run_kitti_gs.yaml
+    "surfel_direct": ("gaussian_surfel", False, False, False),
+    "surfel_view_dist": ("gaussian_surfel", False, True, True),
+    "gs3d_res_view": ("3d_gs", True, True, False),
+}
+
+
+def make_spawn(R):
+    for name, (gs_type, residual, view_on, dist_on) in SPAWN_CASES.items():
+        gen = torch.Generator().manual_seed(11 + len(name))
+        torch.manual_seed(5)
+        cfg = R.make_config(feature_dim=32, color_feature_dim=16, gs_mlp_hidden_dim=128, bs=4096)
+        cfg.infer_bs = 100  # force several chunks inside Decoder.mlp_batch (decoder.py:84-98)
+        K = 8
+        mk = lambda fin, out, pos: R.Decoder(cfg, fin, cfg.gs_mlp_hidden_dim, 1, out, K, pos)
+        decoders = {"gauss_xyz": mk(32, 3, 0), "gauss_rot": mk(32, 4, 0), "gauss_scale": mk(32, 3, 0),
+                    "gauss_alpha": mk(32, 1, 1 if dist_on else 0), "gauss_color": mk(16, 3, 3 if view_on else 0)}
+        N = 260
+        pos = (torch.rand(N, 3, generator=gen) - 0.5) * 8
+        ori = torch.nn.functional.normalize(torch.randn(N, 4, generator=gen), dim=1)
+        ori[: N // 2] = torch.tensor([1.0, 0, 0, 0])          # identity until a loop closure
+        col = torch.rand(N, 3, generator=gen)
+        geo = (0.5 * torch.randn(N + 1, 32, generator=gen)).requires_grad_(True)
+        cfe = (0.5 * torch.randn(N + 1, 16, generator=gen)).requires_grad_(True)
+        vis = torch.rand(N, generator=gen) > 0.25
+        valid = torch.rand(N, generator=gen) > 0.1
+        free = torch.rand(N, generator=gen) > 0.8
+        data = {"position": pos, "orientation": ori, "color": col, "geo_feature": geo, "color_feature": cfe,
+                "resolution": 0.25, "free_mask": free, "valid_mask": valid,
+                "stability": torch.rand(N, generator=gen)}
+        cam = torch.tensor([0.3, -0.2, 0.5])
+        res = R.spawn_gaussians(data, decoders, vis, cam, dist_on, view_on, z_far=60.0,
+                                learn_color_residual=residual, gs_type=gs_type, displacement_range_ratio=2.0,
+                                max_scale_ratio=2.0, unit_scale_ratio=0.5)
+        keys = ["gaussian_xyz", "gaussian_scale", "gaussian_rot", "gaussian_alpha", "gaussian_color"]
+        wts = {k: torch.randn(res[k].shape, generator=gen) for k in keys}
+        w_all = torch.randn(res["alpha_all"].shape, generator=gen)
+        loss = sum((res[k] * wts[k]).sum() for k in keys) + (res["alpha_all"] * w_all).sum()
+        params = [p_ for d in decoders.values() for p_ in d.parameters()]
+        grads = torch.autograd.grad(loss, [geo, cfe] + params)
+        out = dict(position=_np(pos), orientation=_np(ori), color=_np(col), geo_feature=_np(geo), color_feature=_np(cfe),
+                   resolution=np.float64(0.25), free_mask=_np(free), valid_mask=_np(valid), visible_mask=_np(vis),
+                   cam_origin=_np(cam), z_far=np.float64(60.0), K=np.int64(K), infer_bs=np.int64(cfg.infer_bs),
+                   gs_type=np.str_(gs_type), learn_color_residual=np.bool_(residual), view_concat_on=np.bool_(view_on),
+                   dist_concat_on=np.bool_(dist_on), displacement_range_ratio=np.float64(2.0),
+                   max_scale_ratio=np.float64(2.0), unit_scale_ratio=np.float64(0.5),
+                   w_alpha_all=_np(w_all), loss=_np(loss), local_view_gaussian_count=np.int64(res["local_view_gaussian_count"]),
+                   gaussian_free_mask=_np(res["gaussian_free_mask"]), alpha_all=_np(res["alpha_all"]),
+                   d_geo_feature=_np(grads[0]), d_color_feature=_np(grads[1]))
+        for k in keys:
+            out[k] = _np(res[k])
+            out["w_" + k] = _np(wts[k])
+        gi = 2
+        for dn, d in decoders.items():
+            for pn, p_ in d.named_parameters():
+                out[f"dec.{dn}.{pn}"] = _np(p_)
+                out[f"d_dec.{dn}.{pn}"] = _np(grads[gi])
+                gi += 1
+        np.savez_compressed(OUT / f"spawn_{name}.npz", **out)
+        print(f"spawn_{name}: spawned {res['local_view_gaussian_count']} of {res['alpha_all'].shape[0]} loss={loss.item():.4f}")
+    # fewer than 10 visible neural points -> None (gaussian_renderer/__init__.py:572)
+    data_small = {k: (v[:8] if torch.is_tensor(v) and v.shape[0] == N else v) for k, v in data.items()}
+    data_small["geo_feature"] = geo[:9]
+    data_small["color_feature"] = cfe[:9]
+    assert R.spawn_gaussians(data_small, decoders, None, cam, dist_on, view_on, gs_type=gs_type) is None
+
+
+GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn}
 
 
 def main(argv):
