@@ -250,7 +250,43 @@ def make_spawn(R):
     assert R.spawn_gaussians(data_small, decoders, None, cam, dist_on, view_on, gs_type=gs_type) is None
 
 
-GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn}
+
+# ---------------------------------------------------------------- G6/G7 camera conventions
+def make_camera(R):
+    """G6: CamImage matrices + depth2normal; G7: update_pose."""
+    gen = torch.Generator().manual_seed(77)
+    cases = {"centered": (320, 240, 250.0, 255.0, 159.5, 119.5), "offcentre": (200, 120, 180.0, 175.0, 87.3, 71.9)}
+    for name, (W, H, fx, fy, cx, cy) in cases.items():
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float64)
+        w = torch.randn(3, generator=gen, dtype=torch.float64) * 0.3
+        Wm = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
+        pose = torch.eye(4, dtype=torch.float64)
+        pose[:3, :3] = torch.linalg.matrix_exp(Wm)
+        pose[:3, 3] = torch.randn(3, generator=gen, dtype=torch.float64)
+        cam = R.CamImage(3, None, K, z_min=0.05, z_max=80.0, device="cpu", cam_pose=pose, img_width=W, img_height=H)
+        depth = 2.0 + torch.rand(1, H // 2, W // 2, generator=gen) + \
+            0.01 * torch.arange(W // 2, dtype=torch.float32)[None, None, :]
+        mask = torch.rand(1, H // 2, W // 2, generator=gen) > 0.1
+        n = R.depth2normal(depth, mask, cam, img_scale=2)
+        out = dict(W=np.int64(W), H=np.int64(H), K=K, z_min=np.float64(0.05), z_max=np.float64(80.0), pose=_np(pose),
+                   FoVx=np.float64(cam.FoVx), FoVy=np.float64(cam.FoVy), prcppoint=_np(cam.prcppoint),
+                   projection_matrix=_np(cam.projection_matrix), world_view_transform=_np(cam.world_view_transform),
+                   full_proj_transform=_np(cam.full_proj_transform), camera_center=_np(cam.camera_center),
+                   full_patch_d1=_np(cam.full_patch(1)), d2n_depth=_np(depth), d2n_mask=_np(mask), d2n_normal=_np(n))
+        # G7: left-multiplied SE3 increment (campose_utils.py:79-98), small and large tau
+        for tag, scale in (("small", 1e-3), ("large", 0.4)):
+            cam2 = R.CamImage(3, None, K, z_min=0.05, z_max=80.0, device="cpu", cam_pose=pose, img_width=W, img_height=H)
+            tau = torch.randn(6, generator=gen) * scale
+            cam2.cam_trans_delta.data.copy_(tau[:3])
+            cam2.cam_rot_delta.data.copy_(tau[3:])
+            R.update_pose(cam2)
+            out[f"tau_{tag}"] = _np(tau)
+            out[f"wvt_after_{tag}"] = _np(cam2.world_view_transform)
+        np.savez_compressed(OUT / f"camera_{name}.npz", **out)
+        print(f"camera_{name}: ok")
+
+
+GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera}
 
 
 def main(argv):

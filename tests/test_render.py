@@ -1,0 +1,113 @@
+"""End-to-end `render` (markVisible -> spawn -> rasterise -> exposure) on the GPU against the oracle chain."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import raster_cpu as R
+from test_spawn import Dec  # duck-typed Decoder
+
+
+def _scene(device, gs_type="gaussian_surfel", n=900, K=4, seed=3):
+    from pings_amd.camera import Camera
+
+    g = torch.Generator().manual_seed(seed)
+    xy = (torch.rand(n, 2, generator=g) - 0.5) * 6
+    pos = torch.stack([xy[:, 0], xy[:, 1], 4.0 + 0.5 * torch.sin(xy[:, 0])], 1)
+    pos[:60, 2] = -3.0  # behind the camera
+    quat = torch.tensor([1.0, 0, 0, 0]).repeat(n, 1)
+    st = {}
+
+    def mk(name, fin, out):
+        st[f"dec.{name}.layers.0.weight"] = (torch.randn(64, fin, generator=g) / fin ** 0.5).numpy()
+        st[f"dec.{name}.layers.0.bias"] = (0.1 * torch.randn(64, generator=g)).numpy()
+        st[f"dec.{name}.lout.weight"] = (torch.randn(out * K, 64, generator=g) / 8).numpy()
+        st[f"dec.{name}.lout.bias"] = (0.1 * torch.randn(out * K, generator=g)).numpy()
+
+    for name, fin, out in [("gauss_xyz", 16, 3), ("gauss_rot", 16, 4), ("gauss_scale", 16, 3), ("gauss_alpha", 16, 1),
+                           ("gauss_color", 8 + 3, 3)]:
+        mk(name, fin, out)
+    decs = {nm: Dec(st, nm, K, device) for nm in ["gauss_xyz", "gauss_rot", "gauss_scale", "gauss_alpha", "gauss_color"]}
+    geo = (0.5 * torch.randn(n + 1, 16, generator=g)).to(device).requires_grad_(True)
+    cfe = (0.5 * torch.randn(n + 1, 8, generator=g)).to(device).requires_grad_(True)
+    data = {"position": pos.to(device), "orientation": quat.to(device), "color": torch.rand(n, 3, generator=g).to(device),
+            "geo_feature": geo, "color_feature": cfe, "resolution": 0.25,
+            "free_mask": torch.zeros(n, dtype=torch.bool, device=device),
+            "valid_mask": torch.ones(n, dtype=torch.bool, device=device)}
+    cam = Camera(160, 96, 140.0, 150.0, 78.3, 49.1, 0.05, 60.0, torch.eye(4, dtype=torch.float64), device=device)
+    return data, decs, cam, geo, cfe
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gs_type", ["gaussian_surfel", "3d_gs"])
+def test_render_end_to_end_matches_oracle_chain(gs_type):
+    from pings_amd.renderer import render, spawn_gaussians
+
+    dev = "cuda"
+    data, decs, cam, geo, cfe = _scene(dev, gs_type)
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    with torch.no_grad():
+        cam.exposure_mat.copy_(torch.eye(3, device=dev) * 0.9 + 0.05)
+        cam.exposure_offset.copy_(torch.tensor([0.01, -0.02, 0.03], device=dev))
+    pkg = render(cam, None, data, decs, None, bg, view_concat_on=True, learn_color_residual=True, front_only_on=False,
+                 d2n_on=True, gs_type=gs_type, displacement_range_ratio=2.0, max_scale_ratio=2.0, unit_scale_ratio=0.5)
+    for k in ["render", "surf_depth", "rend_alpha", "surf_normal", "viewspace_points", "visibility_filter", "radii",
+              "gaussian_xyz", "alpha_all", "local_view_gaussian_count", "visible_neural_point_ratio"]:
+        assert k in pkg, k
+    assert pkg["render"].shape == (3, 96, 160) and pkg["surf_depth"].shape == (1, 96, 160)
+    assert 0.0 < pkg["visible_neural_point_ratio"] < 1.0
+    if gs_type == "gaussian_surfel":
+        assert pkg["rend_normal"].shape == (3, 96, 160) and "contributions" in pkg
+    else:
+        assert pkg["rend_normal"] is None
+
+    # oracle chain on the very Gaussians that were spawned (fp64)
+    dt = torch.float64
+    c = lambda t: t.detach().cpu().to(dt)
+    s = R.Settings(96, 160, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), c(bg), 1.0, c(cam.world_view_transform),
+                   c(cam.full_proj_transform), c(cam.projection_matrix), c(cam.prcppoint), front_only=False,
+                   mode="surfel" if gs_type == "gaussian_surfel" else "3dgs")
+    o = R.rasterize(c(pkg["gaussian_xyz"]), c(pkg["gaussian_color"]), c(pkg["gaussian_alpha"]), c(pkg["gaussian_scale"]),
+                    c(pkg["gaussian_rot"]), s)
+    img = o["color"].permute(1, 2, 0).reshape(-1, 3) @ c(cam.exposure_mat).T + c(cam.exposure_offset)
+    img = img.view(96, 160, 3).permute(2, 0, 1)
+    assert rel_err(pkg["render"], img) <= 1e-4
+    assert rel_err(pkg["rend_alpha"], o["alpha"]) <= 1e-4
+    if gs_type == "gaussian_surfel":
+        assert rel_err(pkg["surf_depth"], o["depth"]) <= 1e-4
+        assert rel_err(pkg["rend_normal"], o["normal"]) <= 1e-4
+    else:  # render() normalises the 3DGS depth in place and zeroes the invisible part (:430,437)
+        vis = o["alpha"] > 1e-3
+        dref = torch.where(vis, o["depth"] / o["alpha"].clamp(min=1e-30), torch.zeros_like(o["depth"]))
+        assert rel_err(pkg["surf_depth"], dref) <= 1e-4
+    assert (pkg["radii"].cpu() == o["radii"]).all()
+
+    # gradients reach the neural-point features, the decoders and the exposure / pose parameters
+    loss = pkg["render"].mean() + 0.1 * pkg["surf_depth"].mean() + 0.05 * pkg["rend_alpha"].mean()
+    loss.backward()
+    assert torch.isfinite(geo.grad).all() and geo.grad.abs().sum() > 0
+    assert torch.isfinite(cfe.grad).all() and cfe.grad.abs().sum() > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for d in decs.values() for p in d.parameters())
+    assert cam.cam_rot_delta.grad is not None and cam.cam_rot_delta.grad.abs().sum() > 0
+    assert cam.exposure_mat.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_render_none_cases():
+    from pings_amd.renderer import render
+
+    dev = "cuda"
+    data, decs, cam, geo, cfe = _scene(dev)
+    bg = torch.ones(3, device=dev)
+    assert render(cam, None, None, decs, None, bg) is None
+    # camera far beyond the scene, looking away from it: nothing visible
+    away = torch.eye(4, dtype=torch.float64)
+    away[2, 3] = 500.0
+    cam.set_pose(away)
+    assert render(cam, None, data, decs, None, bg, view_concat_on=True) is None
+    # too few visible neural points for replay mode
+    cam.set_pose(torch.eye(4, dtype=torch.float64))
+    assert render(cam, None, data, decs, None, bg, view_concat_on=True, min_visible_neural_point_ratio=0.999,
+                  replay_mode=True) is None
+    assert render(cam, None, data, decs, None, bg, view_concat_on=True) is not None
