@@ -278,7 +278,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from pings_amd import _lib, rasterizer as hr
+    from pings_amd import _lib, dist as pdist, rasterizer as hr
 
     L = _lib.lib()
     L.pings_prof_enable.argtypes = [C.c_int]
@@ -332,9 +332,7 @@ def main():
             torch.autograd.backward([img, dep, alp], [gC, gD, gA])
         if world > 1:
             # multi-view step: mean of the per-view parameter gradients, one bucket over RCCL
-            torch.cat([p_.grad.reshape(-1) for p_ in params], out=flat_grad)
-            dist.all_reduce(flat_grad)
-            flat_grad.div_(world)
+            pdist.allreduce_grads(params, bucket=flat_grad)
         stats["visible"] = radii
         return out
 

@@ -1,0 +1,77 @@
+"""Per-view sharding: world_size-2 gloo test on CPU (the N>1 path of bench.py / INTEGRATION.md §5)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pings_amd import dist as pdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        feats = torch.nn.Parameter(torch.randn(50, 8))          # shared neural-point features
+        W = torch.nn.Parameter(torch.randn(8, 3))               # shared decoder
+        expo = torch.nn.Parameter(torch.ones(3))                # per-camera parameter: stays local
+        unused = torch.nn.Parameter(torch.zeros(4))             # never touched on rank 1
+        views = pdist.views_for_rank(4)
+        loss = 0.0
+        for v in views:                                         # each view touches its own subset of points
+            idx = torch.arange(v * 10, v * 10 + 20)
+            loss = loss + ((feats[idx] @ W) * expo).sum() * (v + 1)
+        if rank == 0:
+            loss = loss + unused.sum()
+        loss.backward()
+        local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in (feats, W, unused)]
+        pdist.allreduce_grads([feats, W, unused])
+        sl = pdist.shard_batch(11)
+        part = torch.arange(11.0)[sl] * 2
+        full = pdist.allgather_concat(part)
+        q.put((rank, views, [g.numpy() for g in local], [p.grad.numpy() for p in (feats, W, unused)],
+               expo.grad.numpy(), full.numpy(), (sl.start, sl.stop)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_view_sharding_and_grad_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, v0, l0, g0, e0, f0, s0), (r1, v1, l1, g1, e1, f1, s1) = res
+    assert v0 == [0, 2] and v1 == [1, 3]
+    for a, b, la, lb in zip(g0, g1, l0, l1):
+        assert (a == b).all()                                     # identical on both ranks
+        assert abs(a - (la + lb) / 2).max() < 1e-6                # = mean of the per-rank gradients
+    assert not (e0 == e1).all()                                   # per-camera parameter was not reduced
+    assert (f0 == torch.arange(11.0).numpy() * 2).all() and (f1 == f0).all()
+    assert s0 == (0, 6) and s1 == (6, 11)
+
+
+def test_single_process_is_a_noop():
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    pdist.allreduce_grads([p])
+    assert (p.grad == 2.0).all() and pdist.world() == 1 and pdist.views_for_rank(4) == [0, 1, 2, 3]
+    t = torch.arange(5.0)
+    assert pdist.allgather_concat(t) is t
