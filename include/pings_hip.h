@@ -222,4 +222,23 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
                                 float* grad_x, int64_t* nn_counts, float* certainty, void* stream);
 
+
+/* ------------------------------------------------------ decoder MLP (MFMA)
+ * Replaces `Decoder.mlp` / `Decoder.mlp_batch` (model/decoder.py:62-98) for the one-hidden-level
+ * ReLU decoders every shipped config builds (pings.py:147-172):
+ *     y[N,OUT] = relu(x[N,IN] @ W1[HID,IN]^T + b1[HID]) @ W2[OUT,HID]^T + b2[OUT]
+ * fp32 in / fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain).
+ * Limits: IN <= 64, HID in {32,64,96,128}, OUT <= 32.
+ */
+PINGS_API size_t pings_mlp_backward_scratch_bytes(int IN, int HID, int OUT);
+PINGS_API int pings_mlp_forward(const float* x, int64_t N, int IN, int HID, int OUT, const float* W1,
+                                const float* b1, const float* W2, const float* b2, float* y,
+                                void* stream);
+/* Recomputes the hidden layer (nothing is saved by the forward).  dL_dx may be NULL.  Weight
+ * gradients are per-workgroup partials summed in fixed order (no atomics). */
+PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, int IN, int HID,
+                                 int OUT, const float* W1, const float* b1, const float* W2,
+                                 void* scratch, float* dL_dx, float* dL_dW1, float* dL_db1,
+                                 float* dL_dW2, float* dL_db2, void* stream);
+
 #endif /* PINGS_HIP_H_ */

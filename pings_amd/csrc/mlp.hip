@@ -1,0 +1,367 @@
+// Decoder MLP  y = relu(x W1^T + b1) W2^T + b2  on the gfx950 matrix cores, forward and backward.
+//
+// fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32): bitwise an fp32 fma chain, so the 1e-4 parity
+// bound of the reference's fp32 decoders (model/decoder.py:62-82) holds without mixed precision.
+//
+// Work decomposition: a workgroup has NW = HID/32 waves and walks 32-row tiles of x; wave w owns
+// hidden units 32w .. 32w+31 for ALL products, so every matrix it needs from the previous product is
+// already in its accumulators:
+//   GEMM1 (transposed)  H^T[hid, row]  = W1[hid, :] . x[row, :]^T        A = W1 (LDS), B = x tile (LDS)
+//   GEMM2               Y^T[o, row]   += W2[o, hid] . H^T[hid, row]      B = the GEMM1 accumulator itself
+//                       (accumulator-as-operand: the 32x32 C tile has its column on the lane and its rows
+//                        in the 16 registers, which IS the B-operand layout when k runs over the tile's
+//                        rows in the order (s&3) + 8(s>>2) + 4(lane>>5); the A operand is read from LDS
+//                        in that same k order)
+//   backward            gH^T = (W2^T gY^T) * relu'(H^T) ;  gX^T += W1^T gH^T (B = the gH^T accumulator);
+//                       gW2^T[hid,o] += H^T gY and gW1[hid,i] += gH^T x sum over ROWS, i.e. over the
+//                       accumulators' lane index, so H^T and gH^T take one trip through LDS (transposed
+//                       read) — the only transposes in the kernel.
+// Partial Y^T / gX^T tiles of the NW waves are summed through LDS in fixed order; weight gradients are
+// kept in registers across all row tiles of the workgroup, written as per-workgroup partials and summed
+// by a second kernel in fixed order (bitwise reproducible, no atomics).
+#include "common.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int TR = 32;        // rows per tile
+constexpr int MAX_INP = 64;   // padded input width limit
+constexpr int OUTP = 32;      // padded output width
+
+__device__ inline int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ inline f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct Dims {
+  long long N;
+  int IN, INP, HID, OUT;  // INP = IN rounded up to even
+  int ldw1, ldw2, ldx, ldg;  // LDS leading dimensions (odd -> conflict-free column walks)
+};
+
+__host__ __device__ inline Dims make_dims(long long N, int IN, int HID, int OUT) {
+  Dims d;
+  d.N = N; d.IN = IN; d.HID = HID; d.OUT = OUT;
+  d.INP = (IN + 1) & ~1;
+  d.ldw1 = d.INP + 1;
+  d.ldw2 = HID + 1;
+  d.ldx = d.INP + 1;
+  d.ldg = OUTP + 1;
+  return d;
+}
+
+// ---------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __restrict__ x, const float* __restrict__ W1,
+                               const float* __restrict__ b1, const float* __restrict__ W2,
+                               const float* __restrict__ b2, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NW = d.HID / 32, nthreads = NW * 64;
+  float* sW1 = lds;                                  // [HID][ldw1]
+  float* sW2 = sW1 + d.HID * d.ldw1;                 // [OUTP][ldw2]
+  float* sX = sW2 + OUTP * d.ldw2;                   // [TR][ldx]
+  float* sY = sX + TR * d.ldx;                       // [NW][OUTP][TR+1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  for (int e = tid; e < d.HID * d.INP; e += nthreads) {
+    const int j = e / d.INP, i = e - j * d.INP;
+    sW1[j * d.ldw1 + i] = i < d.IN ? W1[(size_t)j * d.IN + i] : 0.f;
+  }
+  for (int e = tid; e < OUTP * d.HID; e += nthreads) {
+    const int o = e / d.HID, j = e - o * d.HID;
+    sW2[o * d.ldw2 + j] = o < d.OUT ? W2[(size_t)o * d.HID + j] : 0.f;
+  }
+  float bias1[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) bias1[reg] = b1[wave * 32 + rowmap(reg, h)];
+
+  const long long ntiles = (d.N + TR - 1) / TR;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long row0 = t * TR;
+    __syncthreads();  // previous tile's sX / sY consumed (also orders the weight staging on the first trip)
+    for (int e = tid; e < TR * d.INP; e += nthreads) {
+      const int rr = e / d.INP, i = e - rr * d.INP;
+      const long long gr = row0 + rr;
+      sX[rr * d.ldx + i] = (gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc = {0};
+    for (int s = 0; s < d.INP / 2; ++s)
+      acc = mfma(sW1[(wave * 32 + r) * d.ldw1 + 2 * s + h], sX[r * d.ldx + 2 * s + h], acc);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] = fmaxf(acc[reg] + bias1[reg], 0.f);
+    f32x16 acc2 = {0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc2 = mfma(sW2[r * d.ldw2 + wave * 32 + rowmap(s, h)], acc[s], acc2);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) sY[(wave * OUTP + rowmap(reg, h)) * (TR + 1) + r] = acc2[reg];
+    __syncthreads();
+    for (int e = tid; e < TR * d.OUT; e += nthreads) {
+      const int rr = e / d.OUT, o = e - rr * d.OUT;
+      const long long gr = row0 + rr;
+      if (gr < d.N) {
+        float v = b2[o];
+        for (int w = 0; w < NW; ++w) v += sY[(w * OUTP + o) * (TR + 1) + rr];
+        y[(size_t)gr * d.OUT + o] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// scratch layout per workgroup: [HID*IN] gW1, [OUT*HID] gW2, [HID] gb1, [OUT] gb2
+__host__ __device__ inline size_t partial_floats(int IN, int HID, int OUT) {
+  return (size_t)HID * IN + (size_t)OUT * HID + HID + OUT;
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __restrict__ x, const float* __restrict__ gy,
+                               const float* __restrict__ W1, const float* __restrict__ b1,
+                               const float* __restrict__ W2, float* __restrict__ gx,
+                               float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NW = d.HID / 32, nthreads = NW * 64;
+  const int NIB = (d.INP + 31) / 32;                 // 32-wide blocks of the input dimension (1 or 2)
+  float* sW1 = lds;                                  // [HID][ldw1]
+  float* sW2 = sW1 + d.HID * d.ldw1;                 // [OUTP][ldw2]
+  float* sX = sW2 + OUTP * d.ldw2;                   // [TR][ldx]
+  float* sGY = sX + TR * d.ldx;                      // [TR][ldg]
+  float* sHT = sGY + TR * d.ldg;                     // [NW][32 hid][TR+1]
+  float* sGH = sHT + NW * 32 * (TR + 1);             // [NW][32 hid][TR+1]
+  float* sGX = sGH + NW * 32 * (TR + 1);             // [NW][NIB*32][TR+1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  for (int e = tid; e < d.HID * d.INP; e += nthreads) {
+    const int j = e / d.INP, i = e - j * d.INP;
+    sW1[j * d.ldw1 + i] = i < d.IN ? W1[(size_t)j * d.IN + i] : 0.f;
+  }
+  for (int e = tid; e < OUTP * d.HID; e += nthreads) {
+    const int o = e / d.HID, j = e - o * d.HID;
+    sW2[o * d.ldw2 + j] = o < d.OUT ? W2[(size_t)o * d.HID + j] : 0.f;
+  }
+  float bias1[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) bias1[reg] = b1[wave * 32 + rowmap(reg, h)];
+
+  // persistent accumulators of this wave's 32 hidden units
+  f32x16 aW2T = {0};          // gW2^T tile: [hid (rows, reg map)] x [o (lane)]
+  f32x16 aW1a = {0}, aW1b = {0};  // gW1 tiles: [hid] x [i 0..31], [hid] x [i 32..63]
+  f32x16 aB1 = {0};           // per-lane (row) partial of gb1 for hid = rowmap(reg, h)
+  float aB2 = 0.f;            // thread o < OUT of wave 0: column sum of gY
+
+  float* myHT = sHT + wave * 32 * (TR + 1);
+  float* myGH = sGH + wave * 32 * (TR + 1);
+  float* myGX = sGX + wave * NIB * 32 * (TR + 1);
+
+  const long long ntiles = (d.N + TR - 1) / TR;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long row0 = t * TR;
+    __syncthreads();
+    for (int e = tid; e < TR * d.INP; e += nthreads) {
+      const int rr = e / d.INP, i = e - rr * d.INP;
+      const long long gr = row0 + rr;
+      sX[rr * d.ldx + i] = (gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+    }
+    for (int e = tid; e < TR * OUTP; e += nthreads) {
+      const int rr = e / OUTP, o = e - rr * OUTP;
+      const long long gr = row0 + rr;
+      sGY[rr * d.ldg + o] = (gr < d.N && o < d.OUT) ? gy[(size_t)gr * d.OUT + o] : 0.f;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < d.OUT) {
+      float s = 0.f;
+      for (int rr = 0; rr < TR; ++rr) s += sGY[rr * d.ldg + lane];
+      aB2 += s;
+    }
+    // H^T (hidden units of this wave) for the tile's rows
+    f32x16 hT = {0};
+    for (int s = 0; s < d.INP / 2; ++s)
+      hT = mfma(sW1[(wave * 32 + r) * d.ldw1 + 2 * s + h], sX[r * d.ldx + 2 * s + h], hT);
+    // gH^T = W2^T gY^T  (A = W2^T: row = hid on the lane, k = o)
+    f32x16 gT = {0};
+#pragma unroll
+    for (int s = 0; s < OUTP / 2; ++s)
+      gT = mfma(sW2[(2 * s + h) * d.ldw2 + wave * 32 + r], sGY[r * d.ldg + 2 * s + h], gT);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float pre = hT[reg] + bias1[reg];
+      hT[reg] = fmaxf(pre, 0.f);
+      gT[reg] = pre > 0.f ? gT[reg] : 0.f;
+      aB1[reg] += gT[reg];
+    }
+    // gX^T partial of this wave: [i, row] = sum_{hid in wave} W1[hid][i] gH^T[hid][row]
+    //   A = W1^T: row = i on the lane, k = hid in accumulator order; B = the gH^T accumulator
+    if (gx) {
+      for (int ib = 0; ib < NIB; ++ib) {
+        f32x16 ax = {0};
+        const int i = ib * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float a = i < d.INP ? sW1[(wave * 32 + rowmap(s, h)) * d.ldw1 + i] : 0.f;
+          ax = mfma(a, gT[s], ax);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) myGX[(ib * 32 + rowmap(reg, h)) * (TR + 1) + r] = ax[reg];
+      }
+    }
+    // transpose H^T / gH^T through LDS: element [hid (reg map)][row (lane)]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      myHT[rowmap(reg, h) * (TR + 1) + r] = hT[reg];
+      myGH[rowmap(reg, h) * (TR + 1) + r] = gT[reg];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // gW2^T[hid][o] += sum_row H^T[hid][row] gY[row][o]   (A: row = hid on the lane, k = data row)
+    // gW1[hid][i]   += sum_row gH^T[hid][row] x[row][i]
+#pragma unroll
+    for (int s = 0; s < TR / 2; ++s) {
+      const int k = 2 * s + h;
+      const float aH = myHT[r * (TR + 1) + k];
+      const float aG = myGH[r * (TR + 1) + k];
+      aW2T = mfma(aH, sGY[k * d.ldg + r], aW2T);
+      aW1a = mfma(aG, r < d.INP ? sX[k * d.ldx + r] : 0.f, aW1a);
+      if (NIB > 1) aW1b = mfma(aG, (32 + r) < d.INP ? sX[k * d.ldx + 32 + r] : 0.f, aW1b);
+    }
+    __syncthreads();
+    if (gx) {
+      for (int e = tid; e < TR * d.IN; e += nthreads) {
+        const int rr = e / d.IN, i = e - rr * d.IN;
+        const long long gr = row0 + rr;
+        if (gr < d.N) {
+          float v = 0.f;
+          for (int w = 0; w < NW; ++w) v += sGX[(w * NIB * 32 + i) * (TR + 1) + rr];
+          gx[(size_t)gr * d.IN + i] = v;
+        }
+      }
+    }
+  }
+
+  // ---- write this workgroup's partial weight gradients
+  float* P = partials + (size_t)blockIdx.x * partial_floats(d.IN, d.HID, d.OUT);
+  float* pW1 = P;
+  float* pW2 = pW1 + (size_t)d.HID * d.IN;
+  float* pB1 = pW2 + (size_t)d.OUT * d.HID;
+  float* pB2 = pB1 + d.HID;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int hid = wave * 32 + rowmap(reg, h);
+    if (r < d.OUT) pW2[(size_t)r * d.HID + hid] = aW2T[reg];           // lane = o
+    if (r < d.IN) pW1[(size_t)hid * d.IN + r] = aW1a[reg];             // lane = i
+    if (NIB > 1 && 32 + r < d.IN) pW1[(size_t)hid * d.IN + 32 + r] = aW1b[reg];
+  }
+  // gb1: sum the per-row partials over the 32 lanes that share h
+  __syncthreads();
+  float* sRed = sHT;  // reuse: [NW][64 lanes][16]
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) sRed[(wave * 64 + lane) * 17 + reg] = aB1[reg];
+  __syncthreads();
+  for (int e = tid; e < d.HID; e += nthreads) {
+    const int w = e >> 5, m = e & 31;          // hidden unit m of wave w: find (reg, hh) with rowmap = m
+    const int hh = (m >> 2) & 1, reg = (m & 3) + 4 * (m >> 3);
+    float s = 0.f;
+    for (int l = 0; l < 32; ++l) s += sRed[(w * 64 + hh * 32 + l) * 17 + reg];
+    pB1[e] = s;
+  }
+  if (wave == 0 && lane < d.OUT) pB2[lane] = aB2;
+}
+
+__global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblocks, size_t per_block, int IN,
+                                  int HID, int OUT, float* __restrict__ gW1, float* __restrict__ gb1,
+                                  float* __restrict__ gW2, float* __restrict__ gb2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_block) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * per_block + e];
+  const size_t nW1 = (size_t)HID * IN, nW2 = (size_t)OUT * HID;
+  if (e < nW1) gW1[e] = s;
+  else if (e < nW1 + nW2) gW2[e - nW1] = s;
+  else if (e < nW1 + nW2 + HID) gb1[e - nW1 - nW2] = s;
+  else gb2[e - nW1 - nW2 - HID] = s;
+}
+
+int check_dims(int64_t N, int IN, int HID, int OUT) {
+  PINGS_ARG_CHECK(N >= 0, "negative N");
+  PINGS_ARG_CHECK(IN > 0 && IN <= MAX_INP, "IN must be in 1..64");
+  PINGS_ARG_CHECK(HID > 0 && HID <= 128 && HID % 32 == 0, "HID must be 32, 64, 96 or 128");
+  PINGS_ARG_CHECK(OUT > 0 && OUT <= OUTP, "OUT must be in 1..32");
+  return PINGS_OK;
+}
+
+constexpr int MAX_BWD_BLOCKS = 512;
+
+size_t fwd_lds_bytes(const Dims& d) {
+  const int NW = d.HID / 32;
+  return sizeof(float) * ((size_t)d.HID * d.ldw1 + (size_t)OUTP * d.ldw2 + (size_t)TR * d.ldx +
+                          (size_t)NW * OUTP * (TR + 1));
+}
+
+size_t bwd_lds_bytes(const Dims& d) {
+  const int NW = d.HID / 32, NIB = (d.INP + 31) / 32;
+  size_t tail = (size_t)2 * NW * 32 * (TR + 1) + (size_t)NW * NIB * 32 * (TR + 1);
+  const size_t red = (size_t)NW * 64 * 17;  // gb1 reduction reuses the sHT/sGH region
+  if (tail < red) tail = red;
+  return sizeof(float) * ((size_t)d.HID * d.ldw1 + (size_t)OUTP * d.ldw2 + (size_t)TR * d.ldx +
+                          (size_t)TR * d.ldg + tail);
+}
+
+}  // namespace
+
+PINGS_API size_t pings_mlp_backward_scratch_bytes(int IN, int HID, int OUT) {
+  if (IN <= 0 || HID <= 0 || OUT <= 0) return 0;
+  return sizeof(float) * partial_floats(IN, HID, OUT) * MAX_BWD_BLOCKS;
+}
+
+PINGS_API int pings_mlp_forward(const float* x, int64_t N, int IN, int HID, int OUT, const float* W1,
+                                const float* b1, const float* W2, const float* b2, float* y,
+                                void* stream) {
+  if (int e = check_dims(N, IN, HID, OUT)) return e;
+  if (N == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(x && W1 && b1 && W2 && b2 && y, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  const Dims d = make_dims(N, IN, HID, OUT);
+  const long long ntiles = (N + TR - 1) / TR;
+  const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
+  const size_t lds = fwd_lds_bytes(d);
+  PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  pings::prof::Scope ps("mlp_fwd", st);
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid), dim3(64 * (HID / 32)), lds, st, d, x, W1, b1, W2, b2, y);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, int IN, int HID,
+                                 int OUT, const float* W1, const float* b1, const float* W2,
+                                 void* scratch, float* dL_dx, float* dL_dW1, float* dL_db1,
+                                 float* dL_dW2, float* dL_db2, void* stream) {
+  if (int e = check_dims(N, IN, HID, OUT)) return e;
+  PINGS_ARG_CHECK(W1 && b1 && W2 && scratch && dL_dW1 && dL_db1 && dL_dW2 && dL_db2, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  const size_t per_block = partial_floats(IN, HID, OUT);
+  if (N == 0) {
+    PINGS_HIP_CHECK(hipMemsetAsync(dL_dW1, 0, sizeof(float) * HID * IN, st));
+    PINGS_HIP_CHECK(hipMemsetAsync(dL_dW2, 0, sizeof(float) * OUT * HID, st));
+    PINGS_HIP_CHECK(hipMemsetAsync(dL_db1, 0, sizeof(float) * HID, st));
+    PINGS_HIP_CHECK(hipMemsetAsync(dL_db2, 0, sizeof(float) * OUT, st));
+    return PINGS_OK;
+  }
+  PINGS_ARG_CHECK(x && dL_dy, "null pointer");
+  const Dims d = make_dims(N, IN, HID, OUT);
+  const long long ntiles = (N + TR - 1) / TR;
+  const int grid = (int)(ntiles < MAX_BWD_BLOCKS ? ntiles : MAX_BWD_BLOCKS);
+  const size_t lds = bwd_lds_bytes(d);
+  PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  pings::prof::Scope ps("mlp_bwd", st);
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(64 * (HID / 32)), lds, st, d, x, dL_dy, W1, b1, W2,
+                     dL_dx, reinterpret_cast<float*>(scratch));
+  PINGS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
+                     st, reinterpret_cast<const float*>(scratch), grid, per_block, IN, HID, OUT, dL_dW1,
+                     dL_db1, dL_dW2, dL_db2);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
