@@ -191,93 +191,83 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     }
     __syncthreads();
 
+    // Record j-1 is read from LDS while j is processed; per-lane conditions are selects, the only
+    // branches are workgroup- or wave-uniform.
+    float4 a = sA[n - 1], bq = sB[n - 1], c = sC[n - 1], nn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == MODE_SURFEL) nn = sD[n - 1];
     for (int j = n - 1; j >= 0; --j) {
+      const int jn = j > 0 ? j - 1 : 0;
+      const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
+      float4 n_n = nn;
+      if (MODE == MODE_SURFEL) n_n = sD[jn];
+      const float4 ca = a, cb = bq, cc = c, cn = nn;
+      a = a_n; bq = b_n; c = c_n; nn = n_n;
       if (sRow[j] == DEAD_ROW) continue;  // blended nothing in the forward pass (workgroup-uniform)
       const uint32_t idx = (uint32_t)(start + j);
-      bool valid = inside && idx < last;
-      float alpha = 0.f, Gs = 0.f, dx = 0.f, dy = 0.f;
-      float4 a, bq;
-      a = sA[j];
-      bq = sB[j];
-      if (valid) {
-        dx = a.x - pixf_x;
-        dy = a.y - pixf_y;
-        const float power = -0.5f * (bq.x * dx * dx + bq.z * dy * dy) - bq.y * dx * dy;
-        Gs = __expf(power);
-        alpha = fminf(ALPHA_MAX, a.z * Gs);
-        valid = (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      }
+      const float dx = ca.x - pixf_x, dy = ca.y - pixf_y;
+      const float power = -0.5f * (cb.x * dx * dx + cb.z * dy * dy) - cb.y * dx * dy;
+      const float Gs = __expf(power);
+      const float raw = ca.z * Gs;
+      const float alpha = fminf(ALPHA_MAX, raw);
+      const bool valid = inside && idx < last && (power <= 0.0f) && (alpha >= ALPHA_MIN);
       if (!__any(valid)) continue;
 
       float v[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = 0.f;
-      if (valid) {
-        const float one_m = 1.0f - alpha;
-        const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
-        T = T * inv_one_m;
-        const float w = alpha * T;
-        const float4 c = sC[j];
-        float dLda = ((c.x - B0) * gC0 + (c.y - B1) * gC1) + (c.z - B2) * gC2;
-        B0 = fmaf(alpha, c.x - B0, B0);
-        B1 = fmaf(alpha, c.y - B1, B1);
-        B2 = fmaf(alpha, c.z - B2, B2);
-        v[G_R] = gC0 * w;
-        v[G_G] = gC1 * w;
-        v[G_B] = gC2 * w;
-        if (MODE == MODE_SURFEL) {
-          const float4 nn = sD[j];
-          dLda += ((nn.x - BN0) * gN0 + (nn.y - BN1) * gN1) + (nn.z - BN2) * gN2;
-          BN0 = fmaf(alpha, nn.x - BN0, BN0);
-          BN1 = fmaf(alpha, nn.y - BN1, BN1);
-          BN2 = fmaf(alpha, nn.z - BN2, BN2);
-          float gnx = gN0 * w, gny = gN1 * w, gnz = gN2 * w;
-          // per-pixel depth of this surfel
-          const float den = (nn.x * rx + nn.y * ry) + nn.z;
-          const float zlo = a.w - bq.w, zhi = a.w + bq.w;
-          const bool hit = den < -DEN_EPS;
-          const float inv_den = __builtin_amdgcn_rcpf(den);
-          const float d0 = hit ? c.w * inv_den : a.w;
-          const float d = fminf(fmaxf(d0, zlo), zhi);
-          dLda += (d - BD) * gD;
-          BD = fmaf(alpha, d - BD, BD);
-          const float gd = gD * w;
-          if (d0 < zlo) {
-            v[G_ZLO] = gd;
-          } else if (d0 > zhi) {
-            v[G_ZHI] = gd;
-          } else if (hit) {
-            v[G_Q] = gd * inv_den;
-            const float gden = -gd * d0 * inv_den;
-            gnx = fmaf(gden, rx, gnx);
-            gny = fmaf(gden, ry, gny);
-            gnz += gden;
-          } else {
-            v[G_PZ] = gd;
-          }
-          v[G_NX] = gnx;
-          v[G_NY] = gny;
-          v[G_NZ] = gnz;
-        } else {
-          dLda += (a.w - BD) * gD;
-          BD = fmaf(alpha, a.w - BD, BD);
-          v[G_PZ] = gD * w;
-        }
-        dLda = fmaf(dLda, T, coefT * inv_one_m);
-        // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
-        const float raw = a.z * Gs;
-        if (raw <= ALPHA_MAX) {
-          v[G_OPAC] = Gs * dLda;
-          const float dLp = raw * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
-          const float gdx = dLp * (-bq.x * dx - bq.y * dy);
-          const float gdy = dLp * (-bq.z * dy - bq.y * dx);
-          v[G_MX] = gdx;
-          v[G_MY] = gdy;
-          v[G_CONX] = -0.5f * dx * dx * dLp;
-          v[G_CONY] = -dx * dy * dLp;
-          v[G_CONZ] = -0.5f * dy * dy * dLp;
-        }
+      const float one_m = 1.0f - alpha;
+      const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
+      const float Tn = T * inv_one_m;
+      const float w = valid ? alpha * Tn : 0.f;
+      float dLda = ((cc.x - B0) * gC0 + (cc.y - B1) * gC1) + (cc.z - B2) * gC2;
+      const float av = valid ? alpha : 0.f;  // B <- B + alpha (v - B) only for contributing lanes
+      B0 = fmaf(av, cc.x - B0, B0);
+      B1 = fmaf(av, cc.y - B1, B1);
+      B2 = fmaf(av, cc.z - B2, B2);
+      v[G_R] = gC0 * w;
+      v[G_G] = gC1 * w;
+      v[G_B] = gC2 * w;
+      if (MODE == MODE_SURFEL) {
+        dLda += ((cn.x - BN0) * gN0 + (cn.y - BN1) * gN1) + (cn.z - BN2) * gN2;
+        BN0 = fmaf(av, cn.x - BN0, BN0);
+        BN1 = fmaf(av, cn.y - BN1, BN1);
+        BN2 = fmaf(av, cn.z - BN2, BN2);
+        // per-pixel depth of this surfel
+        const float den = (cn.x * rx + cn.y * ry) + cn.z;
+        const float zlo = ca.w - cb.w, zhi = ca.w + cb.w;
+        const bool hit = den < -DEN_EPS;
+        const float inv_den = __builtin_amdgcn_rcpf(den);
+        const float d0 = hit ? cc.w * inv_den : ca.w;
+        const float d = fminf(fmaxf(d0, zlo), zhi);
+        dLda += (d - BD) * gD;
+        BD = fmaf(av, d - BD, BD);
+        const float gd = gD * w;
+        const bool lo = d0 < zlo, hi = d0 > zhi;
+        const bool mid = !lo && !hi;
+        v[G_ZLO] = lo ? gd : 0.f;
+        v[G_ZHI] = hi ? gd : 0.f;
+        const float gq = (mid && hit) ? gd * inv_den : 0.f;
+        v[G_Q] = gq;
+        v[G_PZ] = (mid && !hit) ? gd : 0.f;
+        const float gden = -gq * d0;  // = -gd * d0 / den on the unclamped ray hit, else 0
+        v[G_NX] = fmaf(gden, rx, gN0 * w);
+        v[G_NY] = fmaf(gden, ry, gN1 * w);
+        v[G_NZ] = gN2 * w + gden;
+      } else {
+        dLda += (ca.w - BD) * gD;
+        BD = fmaf(av, ca.w - BD, BD);
+        v[G_PZ] = gD * w;
+        v[G_NX] = 0.f; v[G_NY] = 0.f; v[G_NZ] = 0.f; v[G_Q] = 0.f; v[G_ZLO] = 0.f; v[G_ZHI] = 0.f;
       }
+      dLda = fmaf(dLda, Tn, coefT * inv_one_m);
+      // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
+      dLda = (valid && raw <= ALPHA_MAX) ? dLda : 0.f;
+      v[G_OPAC] = Gs * dLda;
+      const float dLp = raw * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
+      v[G_MX] = dLp * (-cb.x * dx - cb.y * dy);
+      v[G_MY] = dLp * (-cb.z * dy - cb.y * dx);
+      v[G_CONX] = -0.5f * dx * dx * dLp;
+      v[G_CONY] = -dx * dy * dLp;
+      v[G_CONZ] = -0.5f * dy * dy * dLp;
+      T = valid ? Tn : T;
       const float tot = wave_reduce16(v, lane);
       if (lane < 16)
         reinterpret_cast<float*>(&sG[wave][j][0])[((lane & 1) << 3) | ((lane & 2) << 1) | (lane >> 2)] = tot;

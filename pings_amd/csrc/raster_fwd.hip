@@ -45,6 +45,10 @@ static size_t sort_temp_bytes(int64_t n) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                      (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  size_t c = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (uint16_t*)nullptr, (uint16_t*)nullptr,
+                                           (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 16);
+  if (c > a) a = c;
   return align_up(a > b ? a : b) + 256;
 }
 
@@ -250,11 +254,12 @@ __device__ inline int strided_rank(int P) {
 // Emits the (tile id, Gaussian id) instances in depth order.  One lane per Gaussian rank; rects
 // of more than SMALL_RECT tiles are written by the whole wave (coalesced), the rest serially.
 constexpr int SMALL_RECT = 8;
+template <typename KeyT>
 __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
                                                          const uint32_t* __restrict__ gidx_sorted,
                                                          const uint32_t* __restrict__ offsets_sorted,
                                                          uint4* __restrict__ rect,
-                                                         uint32_t* __restrict__ tile_key,
+                                                         KeyT* __restrict__ tile_key,
                                                          uint32_t* __restrict__ gval) {
   const int r = strided_rank(P);
   const int lane = threadIdx.x & 63;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
     uint32_t o = off;
     for (int y = ymin; y < ymax; ++y)
       for (int x = xmin; x < xmax; ++x) {
-        tile_key[o] = (uint32_t)(y * gx + x);
+        tile_key[o] = (KeyT)(y * gx + x);
         gval[o] = g;
         ++o;
       }
@@ -290,17 +295,18 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
     const int wdt = __shfl(xmax, src, 64) - x0;
     for (uint32_t k = lane; k < n; k += 64) {
       const int yy = (int)(k / (uint32_t)wdt), xx = (int)(k - (uint32_t)yy * (uint32_t)wdt);
-      tile_key[o + k] = (uint32_t)((y0 + yy) * gx + (x0 + xx));
+      tile_key[o + k] = (KeyT)((y0 + yy) * gx + (x0 + xx));
       gval[o + k] = gg;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const uint32_t* __restrict__ key,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const KeyT* __restrict__ key,
                                                            uint2* __restrict__ ranges) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I) return;
-  const uint32_t t = key[i];
+  const uint32_t t = (uint32_t)key[i];
   if (i == 0 || key[i - 1] != t) ranges[t].x = (uint32_t)i;
   if (i == I - 1 || key[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
 
   float T = 1.0f;
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
-  uint32_t contributor = 0, last = 0;
+  uint32_t last = 0;
   bool done = !inside;
 
   for (int base = 0; base < todo; base += BLOCK) {
@@ -366,56 +372,50 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
     }
     __syncthreads();
 
+    // Branch-free inner loop: the record of Gaussian j+1 is read from LDS while j is blended, lanes that
+    // skip a Gaussian carry w = 0, and the only branches are wave-uniform.
+    float4 a = sA[0], b = sB[0], c = sC[0], nn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == MODE_SURFEL) nn = sD[0];
     for (int j = 0; j < n; ++j) {
-      // wave-uniform exit once every pixel of this wave is saturated
-      if (__all(done)) break;
-      float w = 0.f;
-      bool touched = false;
-      if (!done) {
-        ++contributor;
-        const float4 a = sA[j];
-        const float4 b = sB[j];
-        const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-        const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-        if (power <= 0.0f) {
-          const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
-          if (alpha >= ALPHA_MIN) {
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < T_EPS) {
-              done = true;
-            } else {
-              w = alpha * T;
-              const float4 c = sC[j];
-              C0 = fmaf(c.x, w, C0);
-              C1 = fmaf(c.y, w, C1);
-              C2 = fmaf(c.z, w, C2);
-              if (MODE == MODE_SURFEL) {
-                const float4 nn = sD[j];
-                const float den = (nn.x * rx + nn.y * ry) + nn.z;
-                float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
-                d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
-                N0 = fmaf(nn.x, w, N0);
-                N1 = fmaf(nn.y, w, N1);
-                N2 = fmaf(nn.z, w, N2);
-                D = fmaf(d, w, D);
-              } else {
-                D = fmaf(a.w, w, D);
-                touched = test_T > 0.5f;
-              }
-              T = test_T;
-              last = contributor;
-            }
-          }
+      const int jn = j + 1 < n ? j + 1 : j;
+      const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
+      float4 n_n = nn;
+      if (MODE == MODE_SURFEL) n_n = sD[jn];
+      if (__all(done)) break;  // every pixel of this wave is saturated
+      const float dx = a.x - pixf_x, dy = a.y - pixf_y;
+      const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
+      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      const float test_T = T * (1.0f - alpha);
+      const bool stop = valid && (test_T < T_EPS);
+      const bool contrib = valid && !stop;
+      done = done || stop;
+      if (__any(contrib)) {
+        const float w = contrib ? alpha * T : 0.f;
+        C0 = fmaf(c.x, w, C0);
+        C1 = fmaf(c.y, w, C1);
+        C2 = fmaf(c.z, w, C2);
+        if (MODE == MODE_SURFEL) {
+          const float den = (nn.x * rx + nn.y * ry) + nn.z;
+          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+          N0 = fmaf(nn.x, w, N0);
+          N1 = fmaf(nn.y, w, N1);
+          N2 = fmaf(nn.z, w, N2);
+          D = fmaf(d, w, D);
+        } else {
+          D = fmaf(a.w, w, D);
         }
-      }
-      if (__any(w != 0.f)) {
+        T = contrib ? test_T : T;
+        last = contrib ? (uint32_t)(base + j + 1) : last;
         const float s = wave_reduce_sum_dpp(w);
         if ((tid & 63) == 63) sAcc[tid >> 6][j] = s;
         if (MODE == MODE_3DGS) {
-          const unsigned long long m = __ballot(touched);
+          const unsigned long long m = __ballot(contrib && test_T > 0.5f);
           if ((tid & 63) == 0) sCnt[tid >> 6][j] = (uint32_t)__popcll(m);
         }
       }
+      a = a_n; b = b_n; c = c_n; nn = n_n;
     }
     __syncthreads();
     if (tid < n) {
@@ -626,23 +626,41 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
 
   PINGS_HIP_CHECK(hipMemsetAsync(bs.ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
   if (I > 0) {
+    // tile ids fit 16 bits for every image up to 4096x4096: a 2-byte key cuts the sort traffic by a quarter
+    const bool k16 = num_tiles <= 65536;
+    uint16_t* key16 = reinterpret_cast<uint16_t*>(bs.tile_key);
+    uint16_t* key16s = reinterpret_cast<uint16_t*>(bs.tile_key_sorted);
     {
       pings::prof::Scope ps("duplicate", st);
-      hipLaunchKernelGGL(duplicate_kernel, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P, kp.gx,
-                         gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
+      if (k16)
+        hipLaunchKernelGGL(duplicate_kernel<uint16_t>, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P,
+                           kp.gx, gs.gidx_sorted, gs.offsets_sorted, gs.rect, key16, bs.gval);
+      else
+        hipLaunchKernelGGL(duplicate_kernel<uint32_t>, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P,
+                           kp.gx, gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
       PINGS_LAUNCH_CHECK();
     }
     {
       pings::prof::Scope ps("tile_sort", st);
       size_t tb = bs.temp_bytes;
-      PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key,
-                                                         bs.tile_key_sorted, bs.gval, bs.point_list,
-                                                         (int)I, 0, tile_bits(num_tiles), st));
+      if (k16)
+        PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, key16, key16s, bs.gval,
+                                                           bs.point_list, (int)I, 0, tile_bits(num_tiles),
+                                                           st));
+      else
+        PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key, bs.tile_key_sorted,
+                                                           bs.gval, bs.point_list, (int)I, 0,
+                                                           tile_bits(num_tiles), st));
     }
     {
       pings::prof::Scope ps("tile_ranges", st);
-      hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)),
-                         dim3(256), 0, st, I, bs.tile_key_sorted, bs.ranges);
+      const dim3 rg((unsigned)pings::ceil_div<int64_t>(I, 256));
+      if (k16)
+        hipLaunchKernelGGL(tile_ranges_kernel<uint16_t>, rg, dim3(256), 0, st, I, (const uint16_t*)key16s,
+                           bs.ranges);
+      else
+        hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, rg, dim3(256), 0, st, I,
+                           (const uint32_t*)bs.tile_key_sorted, bs.ranges);
       PINGS_LAUNCH_CHECK();
       PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
       if (s->mode == PINGS_RASTER_3DGS)
