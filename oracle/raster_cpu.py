@@ -29,7 +29,8 @@ listed in DESIGN.md ("rasteriser semantics"): 16x16 tiles, sort key (tile, view
 depth) with ties broken by Gaussian index, 3-sigma radius, z <= 0.2 near cull,
 T < 1e-4 termination, `contributions` = sum of blend weights over pixels,
 depth normalised by max(alpha, 1e-10), un-normalised blended normals, the
-per-pixel depth clamp to +-3*max(scale) around the centre depth.
+per-pixel depth clamp to +-3*max(scale) around the centre depth, tile rectangles = bounding
+box of the footprint ellipse cut at min(3 sigma, alpha = 1/255) (`radii` stays ceil(3 sqrt(lambda_max))).
 
 The same code runs in float32 (to pin tile rectangles, radii and the sort order
 bit-exactly: the op order below is the one the HIP preprocess kernel follows,
@@ -100,7 +101,7 @@ def _se3_delta(theta, rho):
     return Rd, Vd @ rho
 
 
-def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None):
+def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None, opacities=None):
     """Per-Gaussian geometry.  Returns a dict of [P] / [P,k] tensors; `valid` marks
     Gaussians that survive culling (radius > 0)."""
     dt = means3D.dtype
@@ -167,14 +168,23 @@ def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None):
 
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     with torch.no_grad():
+        # Tile rectangle = axis-aligned bounding box of the footprint ellipse, cut at 3 sigma and at the
+        # radius where alpha falls below 1/255:  k^2 = min(9, 2 ln(255 o));  ex = k sqrt(cov_xx), ey = k sqrt(cov_yy).
+        # A Gaussian whose peak alpha is below 1/255 touches nothing.
+        if opacities is None:
+            k2 = torch.full_like(mx, 9.0)
+        else:
+            k2 = torch.clamp(2.0 * torch.log(255.0 * opacities.reshape(-1).detach()), max=9.0)
         def _tile(v, hi):
-            return torch.clamp(torch.trunc(v / TILE), 0, hi).to(torch.int64)
-        safe = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius)
+            return torch.clamp(torch.floor(v / TILE), 0, hi).to(torch.int64)
+        safe = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius) & (k2 > 0)
+        k2s = torch.where(safe, k2, torch.zeros_like(k2))
         mxs = torch.where(safe, mx, torch.zeros_like(mx))
         mys = torch.where(safe, my, torch.zeros_like(my))
-        rs = torch.where(safe, radius, torch.zeros_like(radius))
-        xmin, xmax = _tile(mxs - rs, gx), _tile(mxs + rs + (TILE - 1), gx)
-        ymin, ymax = _tile(mys - rs, gy), _tile(mys + rs + (TILE - 1), gy)
+        ex = torch.sqrt(k2s * torch.where(safe, cxx, torch.zeros_like(cxx)))
+        ey = torch.sqrt(k2s * torch.where(safe, cyy, torch.zeros_like(cyy)))
+        xmin, xmax = _tile(mxs - ex, gx), _tile((mxs + ex) + TILE, gx)
+        ymin, ymax = _tile(mys - ey, gy), _tile((mys + ey) + TILE, gy)
         tiles = (xmax - xmin) * (ymax - ymin)
         valid = safe & (tiles > 0)
 
@@ -244,7 +254,7 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
     dt = means3D.dtype
     H, W = s.image_height, s.image_width
     P = means3D.shape[0]
-    geom = preprocess(means3D, scales, rotations, s, theta, rho)
+    geom = preprocess(means3D, scales, rotations, s, theta, rho, opacities)
     g_idx, ranges = bin_and_sort(geom, s)
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     surfel = s.mode == "surfel"

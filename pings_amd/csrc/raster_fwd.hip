@@ -208,14 +208,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     rz = 3.0f * fmaxf(S0, S1);
   }
 
+  // tile rectangle: bounding box of the footprint ellipse, cut at 3 sigma and at alpha = 1/255
+  const float opac = opacities[g];
+  const float k2 = fminf(2.0f * logf(255.0f * opac), 9.0f);
+  ok = ok && (k2 > 0.0f);
   if (ok) {
-    const float msx = mx, msy = my;
-    int xmin = (int)truncf((msx - radius) / (float)TILE);
-    int xmax = (int)truncf((msx + radius + (float)(TILE - 1)) / (float)TILE);
-    int ymin = (int)truncf((msy - radius) / (float)TILE);
-    int ymax = (int)truncf((msy + radius + (float)(TILE - 1)) / (float)TILE);
-    xmin = min(max(xmin, 0), p.gx); xmax = min(max(xmax, 0), p.gx);
-    ymin = min(max(ymin, 0), p.gy); ymax = min(max(ymax, 0), p.gy);
+    const float ex = sqrtf(k2 * cxx), ey = sqrtf(k2 * cyy);
+    const float fgx = (float)p.gx, fgy = (float)p.gy;
+    const int xmin = (int)fminf(fmaxf(floorf((mx - ex) / (float)TILE), 0.0f), fgx);
+    const int xmax = (int)fminf(fmaxf(floorf(((mx + ex) + (float)TILE) / (float)TILE), 0.0f), fgx);
+    const int ymin = (int)fminf(fmaxf(floorf((my - ey) / (float)TILE), 0.0f), fgy);
+    const int ymax = (int)fminf(fmaxf(floorf(((my + ey) + (float)TILE) / (float)TILE), 0.0f), fgy);
     const int tiles = (xmax - xmin) * (ymax - ymin);
     if (tiles > 0) {
       key = __float_as_uint(pz);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   depth_key[g] = key;
   rect[g] = rc;
   radii[g] = rad;
-  rec[4 * g + 0] = make_float4(mx, my, opacities[g], pz);
+  rec[4 * g + 0] = make_float4(mx, my, opac, pz);
   rec[4 * g + 1] = make_float4(conic_x, conic_y, conic_z, rz);
   rec[4 * g + 2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], q);
   rec[4 * g + 3] = make_float4(nx, ny, nz, 0.0f);
