@@ -22,6 +22,8 @@
 // zero gradient where active, min(0.99, .) included).
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "raster_common.hpp"
 
 namespace pings {
@@ -88,8 +90,10 @@ __device__ inline float wave_reduce16(const float (&v)[16], int lane) {
   return r;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
+// PPL = pixels per lane (same lane -> pixel map as blend_fwd_kernel): the 16 gradient terms of a
+// lane's PPL pixels are summed in registers before the wave reduction, which is the expensive part.
+template <int MODE, int PPL>
+__global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint4* __restrict__ rect,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -97,75 +101,87 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const float* __restrict__ inst_w,
     const uint32_t* __restrict__ cidx, float* __restrict__ rows) {
+  constexpr int NT = BLOCK / PPL;
+  constexpr int NWV = NT / 64;
   __shared__ float4 sA[BATCH], sB[BATCH], sC[BATCH], sD[BATCH];
   __shared__ uint32_t sRow[BATCH];  // compact gradient-row index, DEAD_ROW for dead instances
-  __shared__ float4 sG[BLOCK / 64][BATCH][4];
+  __shared__ float4 sG[NWV][BATCH][4];
   __shared__ uint32_t sMax;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int tx = tile % p.gx, ty = tile / p.gx;
-  const int pix_x = tx * TILE + (tid & (TILE - 1));
-  const int pix_y = ty * TILE + (tid >> 4);
-  const bool inside = pix_x < p.W && pix_y < p.H;
-  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const int pix_x = tx * TILE + (lane & (TILE - 1));
+  const int pix_y0 = ty * TILE + wave * 4 * PPL + (lane >> 4);
+  const float pixf_x = (float)pix_x, pixf_y0 = (float)pix_y0;
   const size_t HW = (size_t)p.W * p.H;
-  const size_t pix_id = (size_t)pix_y * p.W + pix_x;
 
-  float rx = 0.f, ry = 0.f;
+  float rx = 0.f, ry[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) ry[k] = 0.f;
   if (MODE == MODE_SURFEL) {
     const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
     const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
     rx = (pixf_x - cxp) / p.fx;
-    ry = (pixf_y - cyp) / p.fy;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(4 * k)) - cyp) / p.fy;
   }
 
   const uint2 range = ranges[tile];
-  uint32_t last = 0;
-  float T_final = 1.f;
-  float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gD = 0.f, coefT = 0.f;
-  if (inside) {
-    last = n_contrib[pix_id];
-    T_final = final_T[pix_id];
-    if (dL_dcolor) {
-      gC0 = dL_dcolor[pix_id];
-      gC1 = dL_dcolor[HW + pix_id];
-      gC2 = dL_dcolor[2 * HW + pix_id];
-    }
-    float gA = dL_dalpha ? dL_dalpha[pix_id] : 0.f;
-    const float gDo = dL_ddepth ? dL_ddepth[pix_id] : 0.f;
-    if (MODE == MODE_SURFEL) {
-      if (dL_dnormal) {
-        gN0 = dL_dnormal[pix_id];
-        gN1 = dL_dnormal[HW + pix_id];
-        gN2 = dL_dnormal[2 * HW + pix_id];
+  uint32_t last[PPL];
+  float T[PPL], gC0[PPL], gC1[PPL], gC2[PPL], gN0[PPL], gN1[PPL], gN2[PPL], gD[PPL], coefT[PPL];
+  float B0[PPL], B1[PPL], B2[PPL], BN0[PPL], BN1[PPL], BN2[PPL], BD[PPL];
+  uint32_t lmax = 0;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    last[k] = 0;
+    T[k] = 1.f;
+    gC0[k] = gC1[k] = gC2[k] = gN0[k] = gN1[k] = gN2[k] = gD[k] = coefT[k] = 0.f;
+    B0[k] = B1[k] = B2[k] = BN0[k] = BN1[k] = BN2[k] = BD[k] = 0.f;
+    const int pix_y = pix_y0 + 4 * k;
+    if (pix_x < p.W && pix_y < p.H) {
+      const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+      last[k] = n_contrib[pix_id];
+      const float T_final = final_T[pix_id];
+      T[k] = T_final;
+      if (dL_dcolor) {
+        gC0[k] = dL_dcolor[pix_id];
+        gC1[k] = dL_dcolor[HW + pix_id];
+        gC2[k] = dL_dcolor[2 * HW + pix_id];
       }
-      const float A = 1.0f - T_final;
-      if (A > DEPTH_ALPHA_EPS) {
-        gD = gDo / A;
-        gA -= gDo * out_depth[pix_id] / A;
+      float gA = dL_dalpha ? dL_dalpha[pix_id] : 0.f;
+      const float gDo = dL_ddepth ? dL_ddepth[pix_id] : 0.f;
+      if (MODE == MODE_SURFEL) {
+        if (dL_dnormal) {
+          gN0[k] = dL_dnormal[pix_id];
+          gN1[k] = dL_dnormal[HW + pix_id];
+          gN2[k] = dL_dnormal[2 * HW + pix_id];
+        }
+        const float A = 1.0f - T_final;
+        if (A > DEPTH_ALPHA_EPS) {
+          gD[k] = gDo / A;
+          gA -= gDo * out_depth[pix_id] / A;
+        }
+      } else {
+        gD[k] = gDo;
       }
-    } else {
-      gD = gDo;
+      const float bgdot = (p.bg[0] * gC0[k] + p.bg[1] * gC1[k]) + p.bg[2] * gC2[k];
+      coefT[k] = (gA - bgdot) * T_final;
     }
-    const float bgdot = (p.bg[0] * gC0 + p.bg[1] * gC1) + p.bg[2] * gC2;
-    coefT = (gA - bgdot) * T_final;
+    lmax = max(lmax, last[k]);
   }
 
   if (tid == 0) sMax = 0u;
   __syncthreads();
   {
-    uint32_t m = last;
+    uint32_t m = lmax;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     if (lane == 0) atomicMax(&sMax, m);
   }
   __syncthreads();
   const int max_last = (int)sMax;
-
-  float T = T_final;
-  float B0 = 0.f, B1 = 0.f, B2 = 0.f, BN0 = 0.f, BN1 = 0.f, BN2 = 0.f, BD = 0.f;
 
   const int nbatch = ceil_div(max_last, BATCH);
   for (int b = nbatch - 1; b >= 0; --b) {
@@ -186,8 +202,7 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
     {
       float4* z = &sG[0][0][0];
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < (BLOCK / 64) * BATCH * 4 / BLOCK; ++k) z[tid + k * BLOCK] = zero;
+      for (int e = tid; e < NWV * BATCH * 4; e += NT) z[e] = zero;
     }
     __syncthreads();
 
@@ -204,85 +219,100 @@ __global__ __launch_bounds__(BLOCK) void blend_bwd_kernel(
       a = a_n; bq = b_n; c = c_n; nn = n_n;
       if (sRow[j] == DEAD_ROW) continue;  // blended nothing in the forward pass (workgroup-uniform)
       const uint32_t idx = (uint32_t)(start + j);
-      const float dx = ca.x - pixf_x, dy = ca.y - pixf_y;
-      const float power = -0.5f * (cb.x * dx * dx + cb.z * dy * dy) - cb.y * dx * dy;
-      const float Gs = __expf(power);
-      const float raw = ca.z * Gs;
-      const float alpha = fminf(ALPHA_MAX, raw);
-      const bool valid = inside && idx < last && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      if (!__any(valid)) continue;
+      const float dx = ca.x - pixf_x;
+      const float p0 = -0.5f * (cb.x * dx * dx);
+      const float pxy = cb.y * dx;
+      float Gs[PPL], raw[PPL], alpha[PPL], dyv[PPL];
+      bool valid[PPL];
+      bool any_v = false;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float dy = ca.y - (pixf_y0 + (float)(4 * k));
+        dyv[k] = dy;
+        const float power = (p0 - 0.5f * (cb.z * dy * dy)) - pxy * dy;
+        Gs[k] = __expf(power);
+        raw[k] = ca.z * Gs[k];
+        alpha[k] = fminf(ALPHA_MAX, raw[k]);
+        valid[k] = idx < last[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+        any_v = any_v || valid[k];
+      }
+      if (!__any(any_v)) continue;
 
       float v[16];
-      const float one_m = 1.0f - alpha;
-      const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
-      const float Tn = T * inv_one_m;
-      const float w = valid ? alpha * Tn : 0.f;
-      float dLda = ((cc.x - B0) * gC0 + (cc.y - B1) * gC1) + (cc.z - B2) * gC2;
-      const float av = valid ? alpha : 0.f;  // B <- B + alpha (v - B) only for contributing lanes
-      B0 = fmaf(av, cc.x - B0, B0);
-      B1 = fmaf(av, cc.y - B1, B1);
-      B2 = fmaf(av, cc.z - B2, B2);
-      v[G_R] = gC0 * w;
-      v[G_G] = gC1 * w;
-      v[G_B] = gC2 * w;
-      if (MODE == MODE_SURFEL) {
-        dLda += ((cn.x - BN0) * gN0 + (cn.y - BN1) * gN1) + (cn.z - BN2) * gN2;
-        BN0 = fmaf(av, cn.x - BN0, BN0);
-        BN1 = fmaf(av, cn.y - BN1, BN1);
-        BN2 = fmaf(av, cn.z - BN2, BN2);
-        // per-pixel depth of this surfel
-        const float den = (cn.x * rx + cn.y * ry) + cn.z;
-        const float zlo = ca.w - cb.w, zhi = ca.w + cb.w;
-        const bool hit = den < -DEN_EPS;
-        const float inv_den = __builtin_amdgcn_rcpf(den);
-        const float d0 = hit ? cc.w * inv_den : ca.w;
-        const float d = fminf(fmaxf(d0, zlo), zhi);
-        dLda += (d - BD) * gD;
-        BD = fmaf(av, d - BD, BD);
-        const float gd = gD * w;
-        const bool lo = d0 < zlo, hi = d0 > zhi;
-        const bool mid = !lo && !hi;
-        v[G_ZLO] = lo ? gd : 0.f;
-        v[G_ZHI] = hi ? gd : 0.f;
-        const float gq = (mid && hit) ? gd * inv_den : 0.f;
-        v[G_Q] = gq;
-        v[G_PZ] = (mid && !hit) ? gd : 0.f;
-        const float gden = -gq * d0;  // = -gd * d0 / den on the unclamped ray hit, else 0
-        v[G_NX] = fmaf(gden, rx, gN0 * w);
-        v[G_NY] = fmaf(gden, ry, gN1 * w);
-        v[G_NZ] = gN2 * w + gden;
-      } else {
-        dLda += (ca.w - BD) * gD;
-        BD = fmaf(av, ca.w - BD, BD);
-        v[G_PZ] = gD * w;
-        v[G_NX] = 0.f; v[G_NY] = 0.f; v[G_NZ] = 0.f; v[G_Q] = 0.f; v[G_ZLO] = 0.f; v[G_ZHI] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = 0.f;
+      const float zlo = ca.w - cb.w, zhi = ca.w + cb.w;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float dy = dyv[k];
+        const float one_m = 1.0f - alpha[k];
+        const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
+        const float Tn = T[k] * inv_one_m;
+        const float w = valid[k] ? alpha[k] * Tn : 0.f;
+        float dLda = ((cc.x - B0[k]) * gC0[k] + (cc.y - B1[k]) * gC1[k]) + (cc.z - B2[k]) * gC2[k];
+        const float av = valid[k] ? alpha[k] : 0.f;  // B <- B + alpha (v - B) only for contributing lanes
+        B0[k] = fmaf(av, cc.x - B0[k], B0[k]);
+        B1[k] = fmaf(av, cc.y - B1[k], B1[k]);
+        B2[k] = fmaf(av, cc.z - B2[k], B2[k]);
+        v[G_R] = fmaf(gC0[k], w, v[G_R]);
+        v[G_G] = fmaf(gC1[k], w, v[G_G]);
+        v[G_B] = fmaf(gC2[k], w, v[G_B]);
+        if (MODE == MODE_SURFEL) {
+          dLda += ((cn.x - BN0[k]) * gN0[k] + (cn.y - BN1[k]) * gN1[k]) + (cn.z - BN2[k]) * gN2[k];
+          BN0[k] = fmaf(av, cn.x - BN0[k], BN0[k]);
+          BN1[k] = fmaf(av, cn.y - BN1[k], BN1[k]);
+          BN2[k] = fmaf(av, cn.z - BN2[k], BN2[k]);
+          // per-pixel depth of this surfel
+          const float den = (cn.x * rx + cn.y * ry[k]) + cn.z;
+          const bool hit = den < -DEN_EPS;
+          const float inv_den = __builtin_amdgcn_rcpf(den);
+          const float d0 = hit ? cc.w * inv_den : ca.w;
+          const float d = fminf(fmaxf(d0, zlo), zhi);
+          dLda += (d - BD[k]) * gD[k];
+          BD[k] = fmaf(av, d - BD[k], BD[k]);
+          const float gd = gD[k] * w;
+          const bool lo = d0 < zlo, hi = d0 > zhi;
+          const bool mid = !lo && !hi;
+          v[G_ZLO] += lo ? gd : 0.f;
+          v[G_ZHI] += hi ? gd : 0.f;
+          const float gq = (mid && hit) ? gd * inv_den : 0.f;
+          v[G_Q] += gq;
+          v[G_PZ] += (mid && !hit) ? gd : 0.f;
+          const float gden = -gq * d0;  // = -gd * d0 / den on the unclamped ray hit, else 0
+          v[G_NX] += fmaf(gden, rx, gN0[k] * w);
+          v[G_NY] += fmaf(gden, ry[k], gN1[k] * w);
+          v[G_NZ] += gN2[k] * w + gden;
+        } else {
+          dLda += (ca.w - BD[k]) * gD[k];
+          BD[k] = fmaf(av, ca.w - BD[k], BD[k]);
+          v[G_PZ] = fmaf(gD[k], w, v[G_PZ]);
+        }
+        dLda = fmaf(dLda, Tn, coefT[k] * inv_one_m);
+        // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
+        dLda = (valid[k] && raw[k] <= ALPHA_MAX) ? dLda : 0.f;
+        v[G_OPAC] = fmaf(Gs[k], dLda, v[G_OPAC]);
+        const float dLp = raw[k] * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
+        v[G_MX] += dLp * (-cb.x * dx - cb.y * dy);
+        v[G_MY] += dLp * (-cb.z * dy - cb.y * dx);
+        v[G_CONX] += -0.5f * dx * dx * dLp;
+        v[G_CONY] += -dx * dy * dLp;
+        v[G_CONZ] += -0.5f * dy * dy * dLp;
+        T[k] = valid[k] ? Tn : T[k];
       }
-      dLda = fmaf(dLda, Tn, coefT * inv_one_m);
-      // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
-      dLda = (valid && raw <= ALPHA_MAX) ? dLda : 0.f;
-      v[G_OPAC] = Gs * dLda;
-      const float dLp = raw * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
-      v[G_MX] = dLp * (-cb.x * dx - cb.y * dy);
-      v[G_MY] = dLp * (-cb.z * dy - cb.y * dx);
-      v[G_CONX] = -0.5f * dx * dx * dLp;
-      v[G_CONY] = -dx * dy * dLp;
-      v[G_CONZ] = -0.5f * dy * dy * dLp;
-      T = valid ? Tn : T;
       const float tot = wave_reduce16(v, lane);
       if (lane < 16)
         reinterpret_cast<float*>(&sG[wave][j][0])[((lane & 1) << 3) | ((lane & 2) << 1) | (lane >> 2)] = tot;
     }
     __syncthreads();
-    {
-      const int j = tid >> 2, part = tid & 3;
-      if (j < n && sRow[j] != DEAD_ROW) {
-        const float4 r0 = sG[0][j][part], r1 = sG[1][j][part], r2 = sG[2][j][part],
-                     r3 = sG[3][j][part];
-        float4 s;
-        s.x = ((r0.x + r1.x) + r2.x) + r3.x;
-        s.y = ((r0.y + r1.y) + r2.y) + r3.y;
-        s.z = ((r0.z + r1.z) + r2.z) + r3.z;
-        s.w = ((r0.w + r1.w) + r2.w) + r3.w;
+    for (int e = tid; e < n * 4; e += NT) {
+      const int j = e >> 2, part = e & 3;
+      if (sRow[j] != DEAD_ROW) {
+        float4 s = sG[0][j][part];
+#pragma unroll
+        for (int wv = 1; wv < NWV; ++wv) {
+          const float4 r1 = sG[wv][j][part];
+          s.x += r1.x; s.y += r1.y; s.z += r1.z; s.w += r1.w;
+        }
         reinterpret_cast<float4*>(rows)[(size_t)sRow[j] * 4 + part] = s;
       }
     }
@@ -691,16 +721,22 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   }
   if (I > 0) {
     pings::prof::Scope ps("blend_bwd", st);
-    if (s->mode == PINGS_RASTER_SURFEL)
-      hipLaunchKernelGGL(blend_bwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
-                         bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
-                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx,
-                         bw.rows);
-    else
-      hipLaunchKernelGGL(blend_bwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, bp,
-                         bs.ranges, bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib,
-                         out_depth, dL_dcolor, dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx,
-                         bw.rows);
+    int ppl = 2;
+    if (const char* e = getenv("PINGS_BLEND_BWD_PPL")) ppl = atoi(e);
+#define PINGS_BLEND_BWD(M, L)                                                                            \
+  hipLaunchKernelGGL((blend_bwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, bp, bs.ranges,    \
+                     bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib, out_depth, dL_dcolor,     \
+                     dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx, bw.rows)
+    if (s->mode == PINGS_RASTER_SURFEL) {
+      if (ppl == 1) PINGS_BLEND_BWD(MODE_SURFEL, 1);
+      else if (ppl == 4) PINGS_BLEND_BWD(MODE_SURFEL, 4);
+      else PINGS_BLEND_BWD(MODE_SURFEL, 2);
+    } else {
+      if (ppl == 1) PINGS_BLEND_BWD(MODE_3DGS, 1);
+      else if (ppl == 4) PINGS_BLEND_BWD(MODE_3DGS, 4);
+      else PINGS_BLEND_BWD(MODE_3DGS, 2);
+    }
+#undef PINGS_BLEND_BWD
     PINGS_LAUNCH_CHECK();
   }
   {

@@ -22,6 +22,7 @@
 // rectangles and the sort order match the fp32 oracle bit for bit.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "raster_common.hpp"
@@ -314,69 +315,90 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const KeyT*
   if (i == I - 1 || key[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
+// PPL = pixels per lane (1, 2 or 4).  A 16x16 tile is covered by 4/PPL waves; lane (x = lane&15,
+// yb = lane>>4) of wave w owns the PPL pixels (x, 4*PPL*w + 4k + yb), k < PPL, which share x: the
+// x-part of the quadratic form, the record unpacking, the loop control and the wave reductions are
+// paid once per lane instead of once per pixel.
+template <int MODE, int PPL>
+__global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint4* __restrict__ rect, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_w,
     uint32_t* __restrict__ inst_cnt) {
+  constexpr int NT = BLOCK / PPL;   // threads per workgroup
+  constexpr int NWV = NT / 64;      // waves per workgroup
   __shared__ float4 sA[BLOCK];  // mx, my, opacity, pz
   __shared__ float4 sB[BLOCK];  // conic, rz
   __shared__ float4 sC[BLOCK];  // rgb, q
   __shared__ float4 sD[BLOCK];  // normal
   __shared__ uint32_t sSlot[BLOCK];
-  __shared__ float sAcc[BLOCK / 64][BLOCK];     // per-wave partial sums of blend weights
-  __shared__ uint32_t sCnt[BLOCK / 64][BLOCK];  // per-wave counts (3DGS n_touched)
+  __shared__ float sAcc[NWV][BLOCK];     // per-wave partial sums of blend weights
+  __shared__ uint32_t sCnt[NWV][BLOCK];  // per-wave counts (3DGS n_touched)
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int tx = tile % p.gx, ty = tile / p.gx;
-  const int pix_x = tx * TILE + (tid & (TILE - 1));
-  const int pix_y = ty * TILE + (tid >> 4);
-  const bool inside = pix_x < p.W && pix_y < p.H;
-  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const int pix_x = tx * TILE + (lane & (TILE - 1));
+  const int pix_y0 = ty * TILE + wave * 4 * PPL + (lane >> 4);
+  const float pixf_x = (float)pix_x, pixf_y0 = (float)pix_y0;
   const size_t HW = (size_t)p.W * p.H;
-  const size_t pix_id = (size_t)pix_y * p.W + pix_x;
 
-  float rx = 0.f, ry = 0.f;
+  float rx = 0.f, ry[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) ry[k] = 0.f;
   if (MODE == MODE_SURFEL) {
     const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
     const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
     rx = (pixf_x - cxp) / p.fx;
-    ry = (pixf_y - cyp) / p.fy;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(4 * k)) - cyp) / p.fy;
   }
 
   const uint2 range = ranges[tile];
   const int todo = (int)(range.y - range.x);
 
-  float T = 1.0f;
-  float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
-  uint32_t last = 0;
-  bool done = !inside;
+  float T[PPL], C0[PPL], C1[PPL], C2[PPL], N0[PPL], N1[PPL], N2[PPL], D[PPL];
+  uint32_t last[PPL];
+  bool inside[PPL], done[PPL];
+  bool all_done = true;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    T[k] = 1.0f;
+    C0[k] = C1[k] = C2[k] = N0[k] = N1[k] = N2[k] = D[k] = 0.f;
+    last[k] = 0;
+    inside[k] = pix_x < p.W && (pix_y0 + 4 * k) < p.H;
+    done[k] = !inside[k];
+    all_done = all_done && done[k];
+  }
 
   for (int base = 0; base < todo; base += BLOCK) {
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(all_done)) break;
     const int n = min(BLOCK, todo - base);
-    if (tid < n) {
-      const uint32_t g = point_list[range.x + base + tid];
-      sA[tid] = rec[4 * (size_t)g + 0];
-      sB[tid] = rec[4 * (size_t)g + 1];
-      sC[tid] = rec[4 * (size_t)g + 2];
-      if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
-      const uint4 rc = rect[g];
-      const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
-      sSlot[tid] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
 #pragma unroll
-      for (int wv = 0; wv < BLOCK / 64; ++wv) {
-        sAcc[wv][tid] = 0.f;
-        if (MODE == MODE_3DGS) sCnt[wv][tid] = 0u;
+    for (int rr = 0; rr < PPL; ++rr) {
+      const int e = tid + rr * NT;
+      if (e < n) {
+        const uint32_t g = point_list[range.x + base + e];
+        sA[e] = rec[4 * (size_t)g + 0];
+        sB[e] = rec[4 * (size_t)g + 1];
+        sC[e] = rec[4 * (size_t)g + 2];
+        if (MODE == MODE_SURFEL) sD[e] = rec[4 * (size_t)g + 3];
+        const uint4 rc = rect[g];
+        const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
+        sSlot[e] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+#pragma unroll
+        for (int wv = 0; wv < NWV; ++wv) {
+          sAcc[wv][e] = 0.f;
+          if (MODE == MODE_3DGS) sCnt[wv][e] = 0u;
+        }
       }
     }
     __syncthreads();
 
-    // Branch-free inner loop: the record of Gaussian j+1 is read from LDS while j is blended, lanes that
-    // skip a Gaussian carry w = 0, and the only branches are wave-uniform.
+    // The record of Gaussian j+1 is read from LDS while j is blended; lanes that skip a Gaussian carry
+    // w = 0 and the only branches are wave-uniform.
     float4 a = sA[0], b = sB[0], c = sC[0], nn = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_SURFEL) nn = sD[0];
     for (int j = 0; j < n; ++j) {
@@ -384,68 +406,103 @@ __global__ __launch_bounds__(BLOCK) void blend_fwd_kernel(
       const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
       float4 n_n = nn;
       if (MODE == MODE_SURFEL) n_n = sD[jn];
-      if (__all(done)) break;  // every pixel of this wave is saturated
-      const float dx = a.x - pixf_x, dy = a.y - pixf_y;
-      const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
-      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      const float test_T = T * (1.0f - alpha);
-      const bool stop = valid && (test_T < T_EPS);
-      const bool contrib = valid && !stop;
-      done = done || stop;
-      if (__any(contrib)) {
-        const float w = contrib ? alpha * T : 0.f;
-        C0 = fmaf(c.x, w, C0);
-        C1 = fmaf(c.y, w, C1);
-        C2 = fmaf(c.z, w, C2);
-        if (MODE == MODE_SURFEL) {
-          const float den = (nn.x * rx + nn.y * ry) + nn.z;
-          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
-          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
-          N0 = fmaf(nn.x, w, N0);
-          N1 = fmaf(nn.y, w, N1);
-          N2 = fmaf(nn.z, w, N2);
-          D = fmaf(d, w, D);
-        } else {
-          D = fmaf(a.w, w, D);
+      if (__all(all_done)) break;  // every pixel of this wave is saturated
+      // power = -0.5 (cx dx^2 + cz dy^2) - cy dx dy ; the dx-only part is shared by the lane's pixels
+      const float dx = a.x - pixf_x;
+      const float p0 = -0.5f * (b.x * dx * dx);
+      const float pxy = b.y * dx;
+      float alpha[PPL], test_T[PPL];
+      bool contrib[PPL];
+      bool any_c = false;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float dy = a.y - (pixf_y0 + (float)(4 * k));  // one rounding, as in the oracle
+        const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+        alpha[k] = fminf(ALPHA_MAX, a.z * __expf(power));
+        const bool valid = !done[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+        test_T[k] = T[k] * (1.0f - alpha[k]);
+        const bool stop = valid && (test_T[k] < T_EPS);
+        contrib[k] = valid && !stop;
+        done[k] = done[k] || stop;
+        any_c = any_c || contrib[k];
+      }
+      if (__any(any_c)) {
+        float wsum = 0.f;
+        uint32_t touched = 0;
+        const float dbase = (MODE == MODE_SURFEL) ? (nn.x * rx + nn.z) : 0.f;
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+          const float w = contrib[k] ? alpha[k] * T[k] : 0.f;
+          wsum += w;
+          C0[k] = fmaf(c.x, w, C0[k]);
+          C1[k] = fmaf(c.y, w, C1[k]);
+          C2[k] = fmaf(c.z, w, C2[k]);
+          if (MODE == MODE_SURFEL) {
+            const float den = (nn.x * rx + nn.y * ry[k]) + nn.z;
+            (void)dbase;
+            float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+            d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+            N0[k] = fmaf(nn.x, w, N0[k]);
+            N1[k] = fmaf(nn.y, w, N1[k]);
+            N2[k] = fmaf(nn.z, w, N2[k]);
+            D[k] = fmaf(d, w, D[k]);
+          } else {
+            D[k] = fmaf(a.w, w, D[k]);
+            touched += (contrib[k] && test_T[k] > 0.5f) ? 1u : 0u;
+          }
+          T[k] = contrib[k] ? test_T[k] : T[k];
+          last[k] = contrib[k] ? (uint32_t)(base + j + 1) : last[k];
         }
-        T = contrib ? test_T : T;
-        last = contrib ? (uint32_t)(base + j + 1) : last;
-        const float s = wave_reduce_sum_dpp(w);
-        if ((tid & 63) == 63) sAcc[tid >> 6][j] = s;
+        const float s = wave_reduce_sum_dpp(wsum);
+        if (lane == 63) sAcc[wave][j] = s;
         if (MODE == MODE_3DGS) {
-          const unsigned long long m = __ballot(contrib && test_T > 0.5f);
-          if ((tid & 63) == 0) sCnt[tid >> 6][j] = (uint32_t)__popcll(m);
+          const uint32_t cnt = wave_reduce_sum_u32_dpp(touched);
+          if (lane == 63) sCnt[wave][j] = cnt;
         }
       }
+      all_done = true;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) all_done = all_done && done[k];
       a = a_n; b = b_n; c = c_n; nn = n_n;
     }
     __syncthreads();
-    if (tid < n) {
-      const float v = ((sAcc[0][tid] + sAcc[1][tid]) + sAcc[2][tid]) + sAcc[3][tid];
-      if (v != 0.f) {  // untouched slots stay at their memset zero
-        inst_w[sSlot[tid]] = v;
-        if (MODE == MODE_3DGS)
-          inst_cnt[sSlot[tid]] = sCnt[0][tid] + sCnt[1][tid] + sCnt[2][tid] + sCnt[3][tid];
+#pragma unroll
+    for (int rr = 0; rr < PPL; ++rr) {
+      const int e = tid + rr * NT;
+      if (e < n) {
+        float v = sAcc[0][e];
+        uint32_t cnt = (MODE == MODE_3DGS) ? sCnt[0][e] : 0u;
+#pragma unroll
+        for (int wv = 1; wv < NWV; ++wv) {
+          v += sAcc[wv][e];
+          if (MODE == MODE_3DGS) cnt += sCnt[wv][e];
+        }
+        if (v != 0.f) {  // untouched slots stay at their memset zero
+          inst_w[sSlot[e]] = v;
+          if (MODE == MODE_3DGS) inst_cnt[sSlot[e]] = cnt;
+        }
       }
     }
   }
 
-  if (inside) {
-    const float A = 1.0f - T;
-    final_T[pix_id] = T;
-    n_contrib[pix_id] = last;
-    out_color[pix_id] = C0 + T * p.bg[0];
-    out_color[HW + pix_id] = C1 + T * p.bg[1];
-    out_color[2 * HW + pix_id] = C2 + T * p.bg[2];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    if (!inside[k]) continue;
+    const size_t pix_id = (size_t)(pix_y0 + 4 * k) * p.W + pix_x;
+    const float A = 1.0f - T[k];
+    final_T[pix_id] = T[k];
+    n_contrib[pix_id] = last[k];
+    out_color[pix_id] = C0[k] + T[k] * p.bg[0];
+    out_color[HW + pix_id] = C1[k] + T[k] * p.bg[1];
+    out_color[2 * HW + pix_id] = C2[k] + T[k] * p.bg[2];
     out_alpha[pix_id] = A;
     if (MODE == MODE_SURFEL) {
-      out_normal[pix_id] = N0;
-      out_normal[HW + pix_id] = N1;
-      out_normal[2 * HW + pix_id] = N2;
-      out_depth[pix_id] = D / fmaxf(A, DEPTH_ALPHA_EPS);
+      out_normal[pix_id] = N0[k];
+      out_normal[HW + pix_id] = N1[k];
+      out_normal[2 * HW + pix_id] = N2[k];
+      out_depth[pix_id] = D[k] / fmaxf(A, DEPTH_ALPHA_EPS);
     } else {
-      out_depth[pix_id] = D;
+      out_depth[pix_id] = D[k];
     }
   }
 }
@@ -672,14 +729,24 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   }
   {
   pings::prof::Scope ps_blend("blend_fwd", st);
-  if (s->mode == PINGS_RASTER_SURFEL)
-    hipLaunchKernelGGL(blend_fwd_kernel<MODE_SURFEL>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
-                       bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
-                       out_alpha, im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt);
-  else
-    hipLaunchKernelGGL(blend_fwd_kernel<MODE_3DGS>, dim3(num_tiles), dim3(BLOCK), 0, st, kp,
-                       bs.ranges, bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth,
-                       out_alpha, im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt);
+  // pixels per lane: more pixels per lane amortise the per-Gaussian overhead but leave fewer waves;
+  // 2 keeps >= 2 waves per tile (PINGS_BLEND_PPL overrides for experiments)
+  int ppl = 2;
+  if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
+#define PINGS_BLEND_FWD(M, L)                                                                          \
+  hipLaunchKernelGGL((blend_fwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, kp, bs.ranges,  \
+                     bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth, out_alpha,      \
+                     im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt)
+  if (s->mode == PINGS_RASTER_SURFEL) {
+    if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
+    else if (ppl == 4) PINGS_BLEND_FWD(MODE_SURFEL, 4);
+    else PINGS_BLEND_FWD(MODE_SURFEL, 2);
+  } else {
+    if (ppl == 1) PINGS_BLEND_FWD(MODE_3DGS, 1);
+    else if (ppl == 4) PINGS_BLEND_FWD(MODE_3DGS, 4);
+    else PINGS_BLEND_FWD(MODE_3DGS, 2);
+  }
+#undef PINGS_BLEND_FWD
   PINGS_LAUNCH_CHECK();
   }
   if (P > 0) {
