@@ -190,7 +190,19 @@ typedef struct pings_knn_map {
   int32_t nn_k;                  /* config.query_nn_k (<= 16)                                  */
   float resolution;              /* voxel size                                                 */
   float max_valid_dist2;         /* 3*((n+1)*res)^2 (:1058)                                    */
+  const void* compact;           /* optional compact mirror of `table` (pings_knn_compact_build); when
+                                    non-NULL the lookups go there (same results, cache resident)  */
+  uint32_t compact_mask;         /* entries - 1                                                */
 } pings_knn_map;
+
+/* Compact, cache-resident mirror of the (>= 99 % empty) dense hash table: open addressing over
+ * `entries` = pings_knn_compact_entries(num_points) 8-byte {slot+1, value} buckets.  A lookup
+ * returns exactly table[slot] (or -1), so results are unchanged; the 81 random gathers of a
+ * query then hit L2 / Infinity Cache instead of missing to HBM.  Rebuild after every change of
+ * `table` (the wrapper keys it on the tensor's version counter). */
+PINGS_API size_t pings_knn_compact_entries(int64_t num_points);
+PINGS_API int pings_knn_compact_build(const int64_t* table, int64_t buffer_size, void* compact,
+                                      size_t entries, void* stream);
 
 /* idx[B,nn_k] (int64, -1 = none; local indices iff global2local != NULL), d2[B,nn_k]
  * (9e3 where idx = -1, :562), nn_counts[B] (int64: valid candidates over all K cells, :557).

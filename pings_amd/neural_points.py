@@ -31,6 +31,7 @@ class _CKnnMap(C.Structure):
         ("use_free_mask", C.c_int32), ("use_valid_mask", C.c_int32),
         ("global2local", C.c_void_p), ("neighbor_dx", C.c_void_p), ("K", C.c_int32), ("nn_k", C.c_int32),
         ("resolution", C.c_float), ("max_valid_dist2", C.c_float),
+        ("compact", C.c_void_p), ("compact_mask", C.c_uint32),
     ]
 
 
@@ -46,6 +47,10 @@ def _declare(L):
     vp = C.c_void_p
     L.pings_knn_search.restype = C.c_int
     L.pings_knn_search.argtypes = [C.POINTER(_CKnnMap), vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.pings_knn_compact_entries.restype = C.c_size_t
+    L.pings_knn_compact_entries.argtypes = [C.c_int64]
+    L.pings_knn_compact_build.restype = C.c_int
+    L.pings_knn_compact_build.argtypes = [vp, C.c_int64, vp, C.c_size_t, vp]
     L.pings_sdf_forward.restype = C.c_int
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
                                     C.c_int64, vp, vp, vp, vp, vp]
@@ -70,6 +75,27 @@ def _dx32(npm):
         cache = (dx, dx.to(torch.int32).contiguous())
         npm._pings_dx32 = cache
     return cache[1]
+
+
+USE_COMPACT_TABLE = True  # set False to read the reference's dense table directly (identical results)
+
+
+def _compact_table(npm):
+    """Cache-resident mirror of `buffer_pt_index`, rebuilt whenever the dense tensor changes
+    (identity + in-place version counter)."""
+    table = npm.buffer_pt_index
+    key = (table.data_ptr(), table._version, table.shape[0])
+    cache = getattr(npm, "_pings_compact", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    L = _L()
+    entries = L.pings_knn_compact_entries(int(npm.neural_points.shape[0]))
+    comp = torch.empty(entries, 2, dtype=torch.int32, device=table.device)
+    st = L.pings_knn_compact_build(_lib.ptr(table.contiguous()), int(table.shape[0]), _lib.ptr(comp), entries,
+                                   _lib.stream_ptr(table.device))
+    _lib.check(st, "pings_knn_compact_build")
+    npm._pings_compact = (key, comp)
+    return comp
 
 
 def _as_u8(mask: torch.Tensor) -> torch.Tensor:
@@ -98,13 +124,15 @@ class _MapArgs:
         valid = _as_u8(npm.valid_gs_mask) if use_valid else None
         g2l = npm.global2local.contiguous() if query_locally else None
         dx = _dx32(npm)
+        comp = _compact_table(npm) if USE_COMPACT_TABLE else None
         self.c = _CKnnMap(
             k(table.contiguous()), int(table.shape[0]), k(npm.neural_points.contiguous()),
             k(ts.contiguous()) if ts is not None else None, k(td) if td is not None else None,
             int(npm.cur_ts), int(bool(time_filtering)), float(npm.diff_travel_dist_local),
             k(free) if free is not None else None, k(valid) if valid is not None else None,
             int(use_free), int(use_valid), k(g2l) if g2l is not None else None, k(dx), int(dx.shape[0]),
-            _nn_k(npm), float(npm.resolution), float(npm.max_valid_dist2))
+            _nn_k(npm), float(npm.resolution), float(npm.max_valid_dist2),
+            k(comp) if comp is not None else None, int(comp.shape[0] - 1) if comp is not None else 0)
         self.device = dev
         self.nn_k = _nn_k(npm)
 
