@@ -292,11 +292,16 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
         dLda = (valid[k] && raw[k] <= ALPHA_MAX) ? dLda : 0.f;
         v[G_OPAC] = fmaf(Gs[k], dLda, v[G_OPAC]);
         const float dLp = raw[k] * dLda;  // dL/dpower = G * (opacity * dL/dalpha)
-        v[G_MX] += dLp * (-cb.x * dx - cb.y * dy);
-        v[G_MY] += dLp * (-cb.z * dy - cb.y * dx);
-        v[G_CONX] += -0.5f * dx * dx * dLp;
-        v[G_CONY] += -dx * dy * dLp;
-        v[G_CONZ] += -0.5f * dy * dy * dLp;
+        // q = conic . d.  d power / d mean = -q, and d power / d cov2D = 0.5 q q^T: accumulating the
+        // gradient w.r.t. the 2-D COVARIANCE here (instead of w.r.t. the conic, to be pushed through
+        // -conic G conic afterwards) keeps every per-pixel term O(1); the conic form sums d d^T terms
+        // of order 1e6 that must cancel to O(1) for large anisotropic footprints, which fp32 cannot do.
+        const float qx = cb.x * dx + cb.y * dy, qy = cb.y * dx + cb.z * dy;
+        v[G_MX] -= dLp * qx;
+        v[G_MY] -= dLp * qy;
+        v[G_CONX] += 0.5f * qx * qx * dLp;
+        v[G_CONY] += qx * qy * dLp;
+        v[G_CONZ] += 0.5f * qy * qy * dLp;
         T[k] = valid[k] ? Tn : T[k];
       }
       const float tot = wave_reduce16(v, lane);
@@ -466,12 +471,10 @@ __global__ __launch_bounds__(256) void gaussian_bwd_kernel(
       const float ca = ((T0[0] * T0[0] + T0[1] * T0[1]) + T0[2] * T0[2]) + LOWPASS;
       const float cb = (T0[0] * T1[0] + T0[1] * T1[1]) + T0[2] * T1[2];
       const float cc = ((T1[0] * T1[0] + T1[1] * T1[1]) + T1[2] * T1[2]) + LOWPASS;
-      const float det = ca * cc - cb * cb;
-      const float id2 = 1.0f / (det * det);
-      const float gcx = G[G_CONX], gcy = G[G_CONY], gcz = G[G_CONZ];
-      const float ga = (-cc * cc * gcx + cb * cc * gcy - cb * cb * gcz) * id2;
-      const float gb = (2.0f * cb * cc * gcx - (ca * cc + cb * cb) * gcy + 2.0f * ca * cb * gcz) * id2;
-      const float gc = (-cb * cb * gcx + ca * cb * gcy - ca * ca * gcz) * id2;
+      // the blend pass accumulated dL/d(cov2D) directly: a = cov_xx, b = cov_xy (the single
+      // off-diagonal parameter), c = cov_yy
+      (void)ca; (void)cb; (void)cc;
+      const float ga = G[G_CONX], gb = G[G_CONY], gc = G[G_CONZ];
       float gT0[3], gT1[3], gMc[3][3];
       float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
 #pragma unroll

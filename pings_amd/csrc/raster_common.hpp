@@ -36,6 +36,7 @@ constexpr int MODE_3DGS = 1;
 
 // 16 floats of per-instance gradient accumulated by the blend backward pass
 // (one 64-B row per (tile, Gaussian) instance, summed per Gaussian afterwards).
+// G_CONX/Y/Z hold dL/d(cov2D xx, xy, yy) — NOT the gradient w.r.t. the conic (see blend_bwd_kernel).
 constexpr int GRAD_ROW = 16;
 enum GradSlot {
   G_MX = 0, G_MY = 1, G_CONX = 2, G_CONY = 3, G_CONZ = 4, G_OPAC = 5,

@@ -265,3 +265,70 @@ def test_dropin_module_names_resolve():
     assert m3.GaussianRasterizationSettings._fields[-1] == "debug"
     assert ms.GaussianRasterizationSettings._fields[-1] == "config"
     assert callable(fs.fused_ssim)
+
+
+@pytest.mark.gpu
+def test_full_size_properties_1m_gaussians_1080p():
+    """BASELINE.json size (1M Gaussians, 1920x1080, the bench.py cloud): size-independent properties —
+    per-tile lists sorted by (depth, index) and consistent with the tile ranges, bounded outputs, background
+    where nothing was blended, backward linear in the upstream gradient, bitwise determinism."""
+    import bench
+    from pings_amd import rasterizer as hr
+
+    dev = torch.device("cuda")
+    P, W, H = 1_000_000, 1920, 1080
+    fx = fy = 1000.0
+    means, col, op, scales, rot = bench.synth_cloud(P, W, H, fx, fy, dev)
+    cam = bench.camera(W, H, fx, fy, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, 0, dev)
+    rs = hr.SurfelRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.ones(3, device=dev),
+        scale_modifier=1.0, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
+        projmatrix_raw=cam["projmatrix_raw"], patch_bbox=torch.tensor([0, 0, H - 1, W - 1], dtype=torch.float32, device=dev),
+        prcppoint=cam["prcppoint"], sh_degree=0, campos=cam["campos"], prefiltered=False, debug=False,
+        config=torch.tensor([1, 1, 1, 1, 1], dtype=torch.float32, device=dev))
+    prep = hr._Prepared(rs, hr.MODE_SURFEL)
+    fs, radii, contrib = hr._forward(prep, means, col, op, scales, rot)
+    pl, rg, fT, nc = hr.debug_lists(fs)
+    # (1) ranges partition the instance list; per-tile depth order, ties by index
+    lens = rg[:, 1] - rg[:, 0]
+    assert int(lens.sum()) == fs.I and int(rg[:, 1].max()) == fs.I
+    depth = (means @ cam["viewmatrix"][:3, 2] + cam["viewmatrix"][3, 2])
+    d = depth[pl]
+    tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), lens)
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool(((d[1:] >= d[:-1]) | ~same).all())
+    tie = same & (d[1:] == d[:-1])
+    assert bool(((pl[1:] > pl[:-1]) | ~tie).all())
+    assert bool((radii[pl] > 0).all()) and bool((depth[pl] > 0.2).all())
+    # (2) bounded outputs
+    assert float(fs.alpha.min()) >= 0 and float(fs.alpha.max()) <= 1.0 + 1e-6
+    assert bool((fs.normal.norm(dim=0) <= fs.alpha[0] + 1e-5).all())
+    assert bool(((fT >= 0) & (fT <= 1)).all()) and bool(torch.allclose(fs.alpha[0], 1 - fT))
+    empty = nc == 0
+    if bool(empty.any()):
+        assert bool((fs.color[:, empty] == 1.0).all()) and bool((fs.depth[0][empty] == 0).all())
+    assert bool((contrib >= 0).all()) and bool((contrib[radii == 0] == 0).all())
+    # total blend weight over Gaussians == total alpha over pixels
+    assert abs(float(contrib.double().sum()) - float(fs.alpha.double().sum())) <= 1e-4 * float(fs.alpha.double().sum())
+    # (3) backward: linear in the upstream gradient, and bitwise reproducible
+    rast = hr.SurfelGaussianRasterizer(rs)
+    g = torch.Generator(device=dev).manual_seed(1)
+    G1 = [torch.randn(c, H, W, generator=g, device=dev) for c in (3, 3, 1, 1)]
+    G2 = [torch.randn(c, H, W, generator=g, device=dev) for c in (3, 3, 1, 1)]
+
+    def grads(Gs):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (means, col, op, scales, rot)]
+        th = torch.zeros(3, device=dev, requires_grad=True)
+        rh = torch.zeros(3, device=dev, requires_grad=True)
+        img, nrm, dep, alp, _, _ = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), colors_precomp=leaves[1],
+                                       opacities=leaves[2], scales=leaves[3], rotations=leaves[4], theta=th, rho=rh)
+        torch.autograd.backward([img, nrm, dep, alp], Gs)
+        return [t.grad for t in leaves] + [th.grad, rh.grad]
+
+    ga, gb = grads(G1), grads(G2)
+    gc = grads([2.0 * a - 0.5 * b for a, b in zip(G1, G2)])
+    for a, b, c in zip(ga, gb, gc):
+        ref = 2.0 * a.double() - 0.5 * b.double()
+        assert (c.double() - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-20)
+    for a, b in zip(ga, grads(G1)):
+        assert torch.equal(a, b)
