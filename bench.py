@@ -208,7 +208,28 @@ def bench_sdf(dev, steps, warmup, n_points=1_000_000, batches=(16384, 131072)):
             train_step()
         torch.cuda.synchronize()
         t_t = (time.perf_counter() - t0) / steps
+        # fused training step: pings_sdf_forward + pings_sdf_backward (deterministic scatter), same loss
+        P_ = [torch.nn.Parameter(t.detach().clone()) for t in W]
+        from types import SimpleNamespace as NS_
+        dec_t = NS_(layers=[NS_(weight=P_[0], bias=P_[1])], lout=NS_(weight=P_[2], bias=P_[3]),
+                    sdf_scale=dec.sdf_scale, use_leaky_relu=False)
+        feats_t = npm.geo_features.detach().clone().requires_grad_(True)
+        npm.local_geo_features = feats_t
+
+        def fused_train_step():
+            s_, _ = hnp.sdf_train(npm, dec_t, x, use_only_measured_points=False)
+            return torch.autograd.grad(s_.abs().mean(), [feats_t] + P_)
+
+        for _ in range(warmup):
+            fused_train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fused_train_step()
+        torch.cuda.synchronize()
+        t_ft = (time.perf_counter() - t0) / steps
         out[f"B{B}"] = {"fwd_fused_Msamples_s": round(B / t_f / 1e6, 2),
+                        "fwd_bwd_fused_Msamples_s": round(B / t_ft / 1e6, 2),
                         "fwd_with_grad_x_Msamples_s": round(B / t_g / 1e6, 2),
                         "fwd_bwd_autograd_Msamples_s": round(B / t_t / 1e6, 2),
                         "fwd_ms": round(t_f * 1e3, 4),

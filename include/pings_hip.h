@@ -232,7 +232,26 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* features, const float* points,
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
-                                float* grad_x, int64_t* nn_counts, float* certainty, void* stream);
+                                float* grad_x, int64_t* nn_counts, float* certainty,
+                                int64_t* idx_out, float* w_out, void* stream);
+/* idx_out[B,nn_k] / w_out[B,nn_k] (optional): the neighbours (in the index space of `features`) and
+ * their normalised inverse-distance weights, kept for pings_sdf_backward. */
+
+/* First-order backward of the fused query w.r.t. the feature table and the decoder
+ * (the training path of Mapper.sdf_mapping, utils/mapper.py:822-970: loss(sdf).backward()).
+ *   dL_dfeatures[rows,F]  dense, zero where no query touched the row
+ *   dL_dW1[H,F+3], dL_db1[H], dL_dW2[H], dL_db2[1]
+ * Deterministic: per-(query, neighbour) gradient rows are written once, sorted by destination
+ * (radix sort) and summed in sorted order; decoder gradients are per-workgroup partials summed in
+ * fixed order.  `scratch` needs pings_sdf_backward_scratch_bytes(B, nn_k, F, H) bytes. */
+PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden);
+PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* features,
+                                 int64_t feature_rows, const float* points,
+                                 const float* orientations, int32_t after_pgo, const float* queries,
+                                 int64_t B, int nn_k, const int64_t* idx, const float* w,
+                                 const float* dL_dsdf, void* scratch, float* dL_dfeatures,
+                                 float* dL_dW1, float* dL_db1, float* dL_dW2, float* dL_db2,
+                                 void* stream);
 
 
 /* ------------------------------------------------------ decoder MLP (MFMA)

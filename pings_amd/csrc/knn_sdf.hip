@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sdf_forward_kernel(
     const float* __restrict__ points, const float* __restrict__ orientations,
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,
     long long B, float* __restrict__ sdf_out, float* __restrict__ grad_out,
-    long long* __restrict__ cnt_out, float* __restrict__ cert_out) {
+    long long* __restrict__ cnt_out, float* __restrict__ cert_out, long long* __restrict__ idx_out,
+    float* __restrict__ w_out) {
   __shared__ long long sIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ long long sGIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ float sD2[WAVES_PER_BLOCK][MAX_NNK];
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sdf_forward_kernel(
     float cert = 0.f;
     if (lane < nnk) {
       sW[wave][lane] = wgt;
+      if (idx_out) idx_out[q * nnk + lane] = my_idx;
+      if (w_out) w_out[q * nnk + lane] = wgt;
       float vx = 0.f, vy = 0.f, vz = 0.f;
       if (my_idx >= 0) {
         vx = qx - points[3 * my_idx];
@@ -504,7 +507,8 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* features, const float* points,
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
-                                float* grad_x, int64_t* nn_counts, float* certainty, void* stream) {
+                                float* grad_x, int64_t* nn_counts, float* certainty,
+                                int64_t* idx_out, float* w_out, void* stream) {
   if (int e = check_map(m)) return e;
   PINGS_ARG_CHECK(dec && dec->W1 && dec->b1 && dec->W2 && dec->b2, "null decoder");
   PINGS_ARG_CHECK(dec->hidden > 0 && dec->hidden <= 64, "hidden must be in 1..64");
@@ -519,7 +523,7 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
 #define PINGS_SDF_LAUNCH(PAD)                                                                          \
   hipLaunchKernelGGL(sdf_forward_kernel<PAD>, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \
                      *dec, features, points, orientations, certainties, (int)after_pgo, queries,       \
-                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty)
+                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out)
   if (in_dim <= 12) PINGS_SDF_LAUNCH(12);
   else if (in_dim <= 36) PINGS_SDF_LAUNCH(36);
   else PINGS_SDF_LAUNCH(64);

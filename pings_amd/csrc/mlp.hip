@@ -273,8 +273,15 @@ __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblock
                                   float* __restrict__ gW2, float* __restrict__ gb2) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per_block) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * per_block + e];
+  // eight independent accumulation chains (fixed assignment -> still deterministic) keep loads in flight
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += partials[(size_t)(b + u) * per_block + e];
+  }
+  for (; b < nblocks; ++b) a[0] += partials[(size_t)b * per_block + e];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   const size_t nW1 = (size_t)HID * IN, nW2 = (size_t)OUT * HID;
   if (e < nW1) gW1[e] = s;
   else if (e < nW1 + nW2) gW2[e - nW1] = s;

@@ -53,7 +53,12 @@ def _declare(L):
     L.pings_knn_compact_build.argtypes = [vp, C.c_int64, vp, C.c_size_t, vp]
     L.pings_sdf_forward.restype = C.c_int
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
-                                    C.c_int64, vp, vp, vp, vp, vp]
+                                    C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+    L.pings_sdf_backward_scratch_bytes.restype = C.c_size_t
+    L.pings_sdf_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.pings_sdf_backward.restype = C.c_int
+    L.pings_sdf_backward.argtypes = [C.POINTER(_CDecoder), vp, C.c_int64, vp, vp, C.c_int32, vp, C.c_int64, C.c_int,
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L._knn_declared = True
 
 
@@ -298,9 +303,84 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     cert = torch.empty(B, dtype=torch.float32, device=dev) if need_certainty else None
     st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(feats), _lib.ptr(pts), _lib.ptr(quat),
                              _lib.ptr(cert_tab), int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf),
-                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), _lib.stream_ptr(dev))
+                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), None, None, _lib.stream_ptr(dev))
     _lib.check(st, "pings_sdf_forward")
     return sdf, grad, cnt, cert
+
+
+class _SdfTrain(torch.autograd.Function):
+    """S(x) with a fused first-order backward to the feature table and the decoder (`pings_sdf_backward`)."""
+
+    @staticmethod
+    def forward(ctx, x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, query_locally, use_meas, use_valid):
+        L = _L()
+        q = x.detach().to(torch.float32).contiguous()
+        B = q.shape[0]
+        a = _MapArgs(npm, bool(npm.temporal_local_map_on and query_locally), use_meas, use_valid, query_locally)
+        f = feats.detach().contiguous()
+        W1c, b1c = W1.detach().contiguous(), b1.detach().contiguous()
+        W2c, b2c = W2.detach().contiguous(), b2.detach().contiguous()
+        F = f.shape[1]
+        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(W1c.shape[0]), int(F),
+                        float(sdf_scale), int(weighted_first))
+        pts = (npm.local_neural_points if query_locally else npm.neural_points).contiguous()
+        quat = (npm.local_point_orientations if query_locally else npm.point_orientations).contiguous()
+        dev = q.device
+        sdf = torch.empty(B, dtype=torch.float32, device=dev)
+        cnt = torch.empty(B, dtype=torch.int64, device=dev)
+        idx = torch.empty(B, a.nn_k, dtype=torch.int64, device=dev)
+        w = torch.empty(B, a.nn_k, dtype=torch.float32, device=dev)
+        need_gx = x.requires_grad
+        gx = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
+        st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(f), _lib.ptr(pts), _lib.ptr(quat), None,
+                                 int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf), _lib.ptr(gx), _lib.ptr(cnt),
+                                 None, _lib.ptr(idx), _lib.ptr(w), _lib.stream_ptr(dev))
+        _lib.check(st, "pings_sdf_forward")
+        ctx.save_for_backward(q, f, W1c, b1c, W2c, b2c, idx, w, pts, quat)
+        ctx.gx = gx
+        ctx.meta = (float(sdf_scale), int(weighted_first), bool(npm.after_pgo), a.nn_k)
+        ctx.mark_non_differentiable(cnt)
+        return sdf, cnt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, _g_cnt):
+        L = _L()
+        q, f, W1c, b1c, W2c, b2c, idx, w, pts, quat = ctx.saved_tensors
+        sdf_scale, weighted_first, after_pgo, nn_k = ctx.meta
+        B, F, H = q.shape[0], f.shape[1], W1c.shape[0]
+        dev = q.device
+        g = g_sdf.detach().to(torch.float32).contiguous()
+        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(H), int(F),
+                        float(sdf_scale), int(weighted_first))
+        f32 = dict(dtype=torch.float32, device=dev)
+        gF = torch.empty_like(f)
+        gW1, gb1 = torch.empty(H, F + 3, **f32), torch.empty(H, **f32)
+        gW2, gb2 = torch.empty(1, H, **f32), torch.empty(1, **f32)
+        scratch = torch.empty(L.pings_sdf_backward_scratch_bytes(B, nn_k, F, H), dtype=torch.uint8, device=dev)
+        st = L.pings_sdf_backward(C.byref(dec), _lib.ptr(f), f.shape[0], _lib.ptr(pts), _lib.ptr(quat), int(after_pgo),
+                                  _lib.ptr(q), B, nn_k, _lib.ptr(idx), _lib.ptr(w), _lib.ptr(g), _lib.ptr(scratch),
+                                  _lib.ptr(gF), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
+                                  _lib.stream_ptr(dev))
+        _lib.check(st, "pings_sdf_backward")
+        gx = ctx.gx * g.unsqueeze(1) if ctx.gx is not None else None
+        return gx, gF, gW1, gb1, gW2, gb2, None, None, None, None, None, None
+
+
+def sdf_train(npm, decoder, x: torch.Tensor, query_locally: bool = True, use_only_measured_points: bool = True,
+              use_only_valid_points: bool = False):
+    """Differentiable `Mapper.sdf(x)` (utils/mapper.py:2273-2289) for the training loop: one fused forward
+    kernel and one fused, deterministic backward to `local_geo_features` and the decoder parameters
+    (first order: use `query_feature` when the loss needs a gradient of the gradient, mapper.py:1448).
+    Returns (sdf[B], nn_counts[B])."""
+    cfg = getattr(npm, "config", None)
+    weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
+    if len(decoder.layers) != 1 or getattr(decoder, "use_leaky_relu", False):
+        raise NotImplementedError("sdf_train supports one-hidden-level ReLU decoders (every shipped config)")
+    feats = npm.local_geo_features if query_locally else npm.geo_features
+    l0, lo = decoder.layers[0], decoder.lout
+    return _SdfTrain.apply(x, feats, l0.weight, l0.bias, lo.weight, lo.bias, npm, float(decoder.sdf_scale),
+                           weighted_first, query_locally, use_only_measured_points, use_only_valid_points)
 
 
 def install(neural_points_cls) -> None:

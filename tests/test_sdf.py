@@ -223,3 +223,41 @@ def test_hip_fused_sdf_large_map_against_oracle():
     # empty batch
     e, _, c, _ = hnp.sdf_fused(gpu, _Dec({**dec}), x[:0].cuda())
     assert e.numel() == 0 and c.numel() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_fused_sdf_backward_matches_oracle_autograd(golden_dir, name):
+    """First-order training gradients (features + decoder) of the fused kernel vs autograd through the oracle
+    (itself pinned to the reference by G1-G3)."""
+    from types import SimpleNamespace as NS
+
+    from pings_amd import neural_points as hnp
+
+    st = load(golden_dir, name)
+    x = T(st["x"])
+    cpu = sdf_cpu.NeuralPointMap(st)
+    dec_c = sdf_cpu.MLP.from_state(st)
+    cpu.local_geo_features.requires_grad_(True)
+    for p in dec_c.parameters():
+        p.requires_grad_(True)
+    s_ref, _ = sdf_cpu.mapper_sdf(cpu, dec_c, x)
+    gw = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(3))
+    ref = torch.autograd.grad((s_ref * gw).sum(), [cpu.local_geo_features] + dec_c.parameters())
+
+    gpu = _gpu_map(st)
+    gpu.local_geo_features.requires_grad_(True)
+    t = lambda k: torch.nn.Parameter(T(st["dec." + k]).cuda())
+    d = NS(layers=[NS(weight=t("layers.0.weight"), bias=t("layers.0.bias"))],
+           lout=NS(weight=t("lout.weight"), bias=t("lout.bias")), sdf_scale=float(st["sdf_scale"]), use_leaky_relu=False)
+    outs = []
+    for _ in range(2):
+        sdf, cnt = hnp.sdf_train(gpu, d, x.cuda())
+        got = torch.autograd.grad((sdf * gw.cuda()).sum(),
+                                  [gpu.local_geo_features, d.layers[0].weight, d.layers[0].bias, d.lout.weight, d.lout.bias])
+        outs.append(got)
+    assert rel_err(sdf, s_ref) <= 1e-4
+    for a, b, nm in zip(outs[0], ref, ["features", "W1", "b1", "W2", "b2"]):
+        assert rel_err(a.reshape(b.shape), b) <= 1e-4, nm          # tolerance: north_star 1e-4 rel
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                                   # bitwise reproducible scatter
