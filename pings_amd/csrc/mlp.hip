@@ -53,6 +53,7 @@ __host__ __device__ inline Dims make_dims(long long N, int IN, int HID, int OUT)
 }
 
 // ---------------------------------------------------------------- forward
+template <int PF_X>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __restrict__ x, const float* __restrict__ W1,
                                const float* __restrict__ b1, const float* __restrict__ W2,
                                const float* __restrict__ b2, float* __restrict__ y) {
@@ -78,15 +79,32 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __res
   for (int reg = 0; reg < 16; ++reg) bias1[reg] = b1[wave * 32 + rowmap(reg, h)];
 
   const long long ntiles = (d.N + TR - 1) / TR;
+  // The next tile of x is fetched into registers while the current one is multiplied (one wave per SIMD:
+  // without this the matrix pipe idles for the whole HBM round trip of every tile).
+  float px[PF_X];
+  auto fetch = [&](long long t) {
+#pragma unroll
+    for (int u = 0; u < PF_X; ++u) {
+      const int e = tid + u * nthreads;
+      const int rr = e / d.INP, i = e - rr * d.INP;
+      const long long gr = t * TR + rr;
+      px[u] = (e < TR * d.INP && gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long long row0 = t * TR;
     __syncthreads();  // previous tile's sX / sY consumed (also orders the weight staging on the first trip)
-    for (int e = tid; e < TR * d.INP; e += nthreads) {
-      const int rr = e / d.INP, i = e - rr * d.INP;
-      const long long gr = row0 + rr;
-      sX[rr * d.ldx + i] = (gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < PF_X; ++u) {
+      const int e = tid + u * nthreads;
+      if (e < TR * d.INP) {
+        const int rr = e / d.INP, i = e - rr * d.INP;
+        sX[rr * d.ldx + i] = px[u];
+      }
     }
     __syncthreads();
+    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
     f32x16 acc = {0};
     for (int s = 0; s < d.INP / 2; ++s)
       acc = mfma(sW1[(wave * 32 + r) * d.ldw1 + 2 * s + h], sX[r * d.ldx + 2 * s + h], acc);
@@ -117,6 +135,7 @@ __host__ __device__ inline size_t partial_floats(int IN, int HID, int OUT) {
   return (size_t)HID * IN + (size_t)OUT * HID + HID + OUT;
 }
 
+template <int PF_X, int PF_G>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __restrict__ x, const float* __restrict__ gy,
                                const float* __restrict__ W1, const float* __restrict__ b1,
                                const float* __restrict__ W2, float* __restrict__ gx,
@@ -157,20 +176,46 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
   float* myGX = sGX + wave * NIB * 32 * (TR + 1);
 
   const long long ntiles = (d.N + TR - 1) / TR;
+  // next tile of x / gY prefetched into registers during the current tile's products
+  float px[PF_X], pg[PF_G];
+  auto fetch = [&](long long t) {
+#pragma unroll
+    for (int u = 0; u < PF_X; ++u) {
+      const int e = tid + u * nthreads;
+      const int rr = e / d.INP, i = e - rr * d.INP;
+      const long long gr = t * TR + rr;
+      px[u] = (e < TR * d.INP && gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PF_G; ++u) {
+      const int e = tid + u * nthreads;
+      const int rr = e / OUTP, o = e - rr * OUTP;
+      const long long gr = t * TR + rr;
+      pg[u] = (e < TR * OUTP && gr < d.N && o < d.OUT) ? gy[(size_t)gr * d.OUT + o] : 0.f;
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long long row0 = t * TR;
     __syncthreads();
-    for (int e = tid; e < TR * d.INP; e += nthreads) {
-      const int rr = e / d.INP, i = e - rr * d.INP;
-      const long long gr = row0 + rr;
-      sX[rr * d.ldx + i] = (gr < d.N && i < d.IN) ? x[(size_t)gr * d.IN + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < PF_X; ++u) {
+      const int e = tid + u * nthreads;
+      if (e < TR * d.INP) {
+        const int rr = e / d.INP, i = e - rr * d.INP;
+        sX[rr * d.ldx + i] = px[u];
+      }
     }
-    for (int e = tid; e < TR * OUTP; e += nthreads) {
-      const int rr = e / OUTP, o = e - rr * OUTP;
-      const long long gr = row0 + rr;
-      sGY[rr * d.ldg + o] = (gr < d.N && o < d.OUT) ? gy[(size_t)gr * d.OUT + o] : 0.f;
+#pragma unroll
+    for (int u = 0; u < PF_G; ++u) {
+      const int e = tid + u * nthreads;
+      if (e < TR * OUTP) {
+        const int rr = e / OUTP, o = e - rr * OUTP;
+        sGY[rr * d.ldg + o] = pg[u];
+      }
     }
     __syncthreads();
+    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
     if (wave == 0 && lane < d.OUT) {
       float s = 0.f;
       for (int rr = 0; rr < TR; ++rr) s += sGY[rr * d.ldg + lane];
@@ -332,10 +377,20 @@ PINGS_API int pings_mlp_forward(const float* x, int64_t N, int IN, int HID, int 
   const long long ntiles = (N + TR - 1) / TR;
   const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
   const size_t lds = fwd_lds_bytes(d);
-  PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // prefetch registers per thread: ceil(32 * INP / threads), in three size classes
+  const int need = (TR * d.INP + 64 * (HID / 32) - 1) / (64 * (HID / 32));
   pings::prof::Scope ps("mlp_fwd", st);
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid), dim3(64 * (HID / 32)), lds, st, d, x, W1, b1, W2, b2, y);
+#define PINGS_MLP_FWD(PX)                                                                                   \
+  do {                                                                                                      \
+    PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<PX>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL(mlp_fwd_kernel<PX>, dim3(grid), dim3(64 * (HID / 32)), lds, st, d, x, W1, b1, W2, b2, y); \
+  } while (0)
+  if (need <= 5) PINGS_MLP_FWD(5);
+  else if (need <= 10) PINGS_MLP_FWD(10);
+  else if (need <= 18) PINGS_MLP_FWD(18);
+  else PINGS_MLP_FWD(32);
+#undef PINGS_MLP_FWD
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
@@ -360,11 +415,22 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
   const long long ntiles = (N + TR - 1) / TR;
   const int grid = (int)(ntiles < MAX_BWD_BLOCKS ? ntiles : MAX_BWD_BLOCKS);
   const size_t lds = bwd_lds_bytes(d);
-  PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nthr = 64 * (HID / 32);
+  const int need = (TR * d.INP + nthr - 1) / nthr;   // x prefetch registers per thread
   pings::prof::Scope ps("mlp_bwd", st);
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(64 * (HID / 32)), lds, st, d, x, dL_dy, W1, b1, W2,
-                     dL_dx, reinterpret_cast<float*>(scratch));
+#define PINGS_MLP_BWD(PX, PG)                                                                              \
+  do {                                                                                                     \
+    PINGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<PX, PG>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+    hipLaunchKernelGGL((mlp_bwd_kernel<PX, PG>), dim3(grid), dim3(nthr), lds, st, d, x, dL_dy, W1, b1, W2,  \
+                       dL_dx, reinterpret_cast<float*>(scratch));                                         \
+  } while (0)
+  // gY prefetch registers: 32*32 / threads = 16, 8, 6, 4 for 1..4 waves
+  if (HID == 128) { if (need <= 5) PINGS_MLP_BWD(5, 4); else if (need <= 9) PINGS_MLP_BWD(9, 4); else PINGS_MLP_BWD(16, 4); }
+  else if (HID == 96) { if (need <= 6) PINGS_MLP_BWD(6, 6); else PINGS_MLP_BWD(11, 6); }
+  else if (HID == 64) { if (need <= 9) PINGS_MLP_BWD(9, 8); else PINGS_MLP_BWD(16, 8); }
+  else { if (need <= 18) PINGS_MLP_BWD(18, 16); else PINGS_MLP_BWD(32, 16); }
+#undef PINGS_MLP_BWD
   PINGS_LAUNCH_CHECK();
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
                      st, reinterpret_cast<const float*>(scratch), grid, per_block, IN, HID, OUT, dL_dW1,
