@@ -73,7 +73,7 @@ def parse_prof(txt):
     return out
 
 
-def cpu_baseline_raster(P_sample=4000, W=240, H=136, threads=None):
+def cpu_baseline_raster(P_sample=16000, W=480, H=272, threads=None):
     """The oracle (kind "port") timed on a bounded sample of the raster workload: the same cloud
     statistics, P_sample Gaussians, WxH pixels, fp32, fwd + autograd bwd, on the host cores."""
     from oracle import raster_cpu as R
@@ -240,7 +240,47 @@ def bench_sdf(dev, steps, warmup, n_points=1_000_000, batches=(16384, 131072)):
     return out, npm, dec
 
 
-def cpu_baseline_sdf(npm, dec, B=16384, reps=3):
+def bench_decoder(dev, steps, warmup, n_points=125_000):
+    """The five spawn decoders (pings.py:156-160; hidden 128, 8 Gaussians per neural point) forward + backward on
+    n_points visible neural points through the MFMA kernel: TFLOP/s against the fp32 matrix peak (157.3 TFLOP/s)."""
+    from pings_amd.mlp import fused_mlp
+    from pings_amd import _lib
+
+    g = torch.Generator(device=dev).manual_seed(3)
+    shapes = [("xyz", 32, 24), ("rot", 32, 32), ("scale", 32, 24), ("alpha", 32, 8), ("color", 19, 24)]
+    nets = []
+    for name, fin, fout in shapes:
+        mk = lambda *s: torch.randn(*s, generator=g, device=dev).requires_grad_(True)
+        nets.append((mk(n_points, fin), mk(128, fin), mk(128), mk(fout, 128), mk(fout), torch.randn(n_points, fout, generator=g, device=dev)))
+
+    def step():
+        for x, W1, b1, W2, b2, gy in nets:
+            y = fused_mlp(x, W1, b1, W2, b2)
+            torch.autograd.grad(y, [x, W1, b1, W2, b2], gy)
+
+    L = _lib.lib()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    L.pings_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    L.pings_prof_enable(0)
+    buf = C.create_string_buffer(4096)
+    L.pings_prof_report(buf, len(buf))
+    prof = parse_prof(buf.value.decode())
+    flop_f = sum(2 * n_points * (fin * 128 + 128 * fout) for _, fin, fout in shapes)
+    t_f, t_b = prof["mlp_fwd"][1] / steps * 1e-3, prof["mlp_bwd"][1] / steps * 1e-3
+    return {"neural_points": n_points, "fwd_ms": round(t_f * 1e3, 4), "bwd_ms": round(t_b * 1e3, 4),
+            "fwd_TFLOPs": round(flop_f / t_f / 1e12, 1), "bwd_TFLOPs": round(2 * flop_f / t_b / 1e12, 1),
+            "mfma_peak_TFLOPs": 157.3, "fwd_frac_of_fp32_mfma_peak": round(flop_f / t_f / 157.3e12, 3),
+            "wall_ms_fwd_bwd_autograd": round(dt * 1e3, 4)}
+
+
+def cpu_baseline_sdf(npm, dec, B=131072, reps=8):
     """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores,
     same map and queries as the GPU run (tensors copied to the host)."""
     from oracle import sdf_cpu
@@ -402,11 +442,17 @@ def main():
                                        params[3].detach(), params[4].detach())
         I = fs.I
         HW = W * H
+        # instances a tile actually blends (front-to-back termination): the units the blend kernels process
+        _, rg_, _, nc_ = hr.debug_lists(fs)
+        gx_, gy_ = math.ceil(W / 16), math.ceil(H / 16)
+        ncp = torch.zeros(gy_ * 16, gx_ * 16, dtype=torch.int32, device=dev)
+        ncp[:H, :W] = nc_
+        I_proc = int(ncp.view(gy_, 16, gx_, 16).permute(0, 2, 1, 3).reshape(gy_ * gx_, 256).max(1).values.sum().item())
         per = {k: v[1] / v[0] for k, v in prof.items()}  # avg ms per launch
         # algorithmic bytes per launch (SURVEY.md §8d terms that belong to each kernel)
         alg = {
-            "blend_bwd": 32 * HW + 8 * HW + 32 * HW + 48 * I,
-            "blend_fwd": 48 * I + 32 * HW + 8 * HW,
+            "blend_bwd": 32 * HW + 8 * HW + 32 * HW + 48 * I_proc,
+            "blend_fwd": 48 * I_proc + 32 * HW + 8 * HW,
             "tile_sort": 24 * I,
             "preprocess": 56 * P + 8 * P,
             "gaussian_bwd": 56 * P + 64 * P,
@@ -432,6 +478,9 @@ def main():
             sdf, npm, dec = bench_sdf(dev, max(args.steps, 5), max(args.warmup, 2))
             if not args.no_cpu_baseline:
                 sdf["cpu_baseline"], _ = cpu_baseline_sdf(npm, dec)
+            del npm, dec
+            torch.cuda.empty_cache()
+        decoder = bench_decoder(dev, max(args.steps, 5), max(args.warmup, 2)) if not args.no_sdf else None
         line = {
             "metric": "raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -439,12 +488,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.mode} rasteriser fwd+bwd, {P} Gaussians, {W}x{H}, one view per GPU"
                                    + (", grad all-reduce (RCCL) of 14 floats/Gaussian" if world > 1 else ""),
-                       "gaussians": P, "width": W, "height": H, "instances": int(I),
+                       "gaussians": P, "width": W, "height": H, "instances": int(I), "instances_blended": I_proc,
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf, "decoder": decoder,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
