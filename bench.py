@@ -65,6 +65,25 @@ def camera(W, H, fx, fy, cx, cy, znear, zfar, rank, device):
     return projection(W, H, fx, fy, cx, cy, znear, zfar, T, device)
 
 
+def pmc_traffic(stage):
+    """HBM bytes per launch of `stage`'s kernel from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN/*pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  PMC counters cannot be read from inside the
+    timed process, so the figure is the one measured when the profile was taken; None if there is none."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("pmc_traffic.json"))
+        if not files:
+            return None, None
+        data = json.load(open(files[-1]))
+        for name, v in data.items():
+            if name.startswith(stage + "_kernel"):
+                return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root))
+    except Exception:
+        pass
+    return None, None
+
+
 def parse_prof(txt):
     out = {}
     for line in txt.strip().splitlines():
@@ -459,8 +478,10 @@ def main():
         }
         dom = max((k for k in per if k in alg), key=lambda k: per[k])
         achieved = alg[dom] / (per[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_ms": round(per[dom], 4), "algorithmic_bytes": int(alg[dom]),
                     "note": "blend kernels are fp32-VALU bound (LDS-broadcast records, ~250 flop per "
                             "fetched byte); see DESIGN.md"}

@@ -1,0 +1,22 @@
+#!/bin/bash
+# One GPU-box pass: parity tests, smoke, bench, rocprofv3 kernel stats, PMC fetch/write passes.
+# usage (from repo root on the box): bash scratch/gpu_round.sh <tag>
+set -o pipefail
+tag=${1:-x}
+R=$PWD
+O=$R/gpurun_out/$tag
+mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 420 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+tail -3 $O/pytest.log
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"
+timeout -k 10 300 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"
+tail -c 600 $O/bench.log
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof.log 2>&1; echo "prof rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+cd $R
+find $O -type f -size +12M -delete
+du -sh $O
+ls -la $O $O/prof 2>/dev/null | head -30
