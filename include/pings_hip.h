@@ -272,4 +272,72 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
                                  void* scratch, float* dL_dx, float* dL_dW1, float* dL_db1,
                                  float* dL_dW2, float* dL_db2, void* stream);
 
+/* ------------------------------------------------------- spawn_gaussians
+ * Replaces the tensor code of `spawn_gaussians` around the five decoder MLPs
+ * (gaussian_splatting/gaussian_renderer/__init__.py:469-778).  Call order for one view:
+ *   pings_spawn_gather   -> dense per-view inputs of the MLPs          (:551-597,:672-675,:692-699)
+ *   5 x pings_mlp_forward
+ *   pings_spawn_plan     -> compacted row of every kept Gaussian + count (alpha > 0, scale filter; :727-761)
+ *   pings_spawn_forward  -> activations + quaternion algebra, written to the compacted rows (:605-716)
+ *   pings_spawn_backward -> gradients back to the raw MLP outputs (autograd of the same lines)
+ * Raw MLP outputs are [n, d*k] row-major == [n*k, d]: Gaussian g = i*k + j of neural point i owns
+ * floats g*d .. g*d+d-1 (the reference's .view(N*K, -1), :632,645,665,687,716).
+ */
+typedef struct {
+  int n;                    /* neural points after the visible & valid mask */
+  int k;                    /* Gaussians per neural point (Decoder.out_k) */
+  int scale_dim;            /* scale-MLP columns per Gaussian (mlp_out_dim / k): 2 or 3 */
+  int surfel;               /* 1: gaussian_surfel -> [s0, s1, 1e-7] (:668-670); 0: 3d_gs -> [s0, s1, s2] */
+  int color_residual;       /* 1: clamp(base + 0.1 tanh(mlp), 0, 1) (:707-711); 0: sigmoid(mlp) (:714) */
+  int alpha_filter_on;      /* keep tanh(alpha mlp) > 0 (:727-740) */
+  int scale_filter_on;      /* keep any(scale > scale_filter_thr) (:747-761) */
+  float displacement_range; /* displacement_range_ratio * resolution (:605) */
+  float unit_scale;         /* unit_scale_ratio * resolution (:661) */
+  float max_scale;          /* max_scale_ratio * resolution (:655) */
+  float scale_filter_thr;   /* scale_filter_ratio * resolution (:751) */
+} pings_spawn_params;
+
+/* Rows `sel[n]` (int64; NULL = rows 0..n-1) of the map tensors -> pos[n,3], quat[n,4], base_color[n,3]
+ * (if `color`), free_out[n] (if `free_mask`), geo_in[n, Fg + dist_concat], col_in[n, Fc + 3*view_concat],
+ * view_dist[n] (nullable).  cam_origin: DEVICE [3] or NULL (then no view features).  xy_only zeroes the
+ * z-component of the view vector before the norm (:592-597); the direction is rotated into the neural
+ * point's frame with R(q) (apply_quaternion_rotation(quat_inverse(q), .), :695-696). */
+PINGS_API int pings_spawn_gather(int n, const int64_t* sel, const float* position, const float* orientation,
+                                 const float* color, const uint8_t* free_mask, const float* geo_feature, int Fg,
+                                 const float* color_feature, int Fc, const float* cam_origin, int xy_only,
+                                 int view_concat, int dist_concat, float* pos, float* quat, float* base_color,
+                                 uint8_t* free_out, float* geo_in, float* col_in, float* view_dist,
+                                 void* stream);
+/* Scatter of the per-view feature gradients (leading dimensions ldg / ldc, first Fg / Fc columns) into
+ * rows `sel` of the map-sized, PRE-ZEROED gradient tensors.  Either pair may be NULL. */
+PINGS_API int pings_spawn_gather_backward(int n, const int64_t* sel, const float* dL_dgeo_in, int Fg, int ldg,
+                                          const float* dL_dcol_in, int Fc, int ldc, float* dL_dgeo_feature,
+                                          float* dL_dcolor_feature, void* stream);
+PINGS_API size_t pings_spawn_plan_scratch_bytes(int64_t num_gaussians);
+/* dest[n*k]: compacted row of every Gaussian or -1 if dropped; *count (device int32) = kept Gaussians.
+ * dist_ratio[n] (nullable) = view_dist / z_far when dist_adaptive_scale (:657-659). */
+PINGS_API int pings_spawn_plan(const pings_spawn_params* p, const float* alpha_raw, const float* scale_raw,
+                               const float* dist_ratio, void* scratch, int32_t* dest, int32_t* count,
+                               void* stream);
+/* dest NULL = no compaction.  Outputs: gaussian_xyz[count,3], gaussian_scale[count, surfel ? 3 : scale_dim],
+ * gaussian_rot[count,4] (wxyz), gaussian_alpha[count,1], gaussian_color[count,3], alpha_all[n*k,1]
+ * (pre-filter, :721), gaussian_free_mask[count] (nullable; Gaussian g takes free_in[g % n], the reference's
+ * tiling at :724). */
+PINGS_API int pings_spawn_forward(const pings_spawn_params* p, const float* xyz_raw, const float* rot_raw,
+                                  const float* scale_raw, const float* alpha_raw, const float* color_raw,
+                                  const float* pos, const float* quat, const float* base_color,
+                                  const float* dist_ratio, const uint8_t* free_in, const int32_t* dest,
+                                  float* gaussian_xyz, float* gaussian_scale, float* gaussian_rot,
+                                  float* gaussian_alpha, float* gaussian_color, float* alpha_all,
+                                  uint8_t* gaussian_free_mask, void* stream);
+/* Any dL_d<output> may be NULL (= zero).  Gradients w.r.t. the raw MLP outputs, same shapes as the inputs. */
+PINGS_API int pings_spawn_backward(const pings_spawn_params* p, const float* xyz_raw, const float* rot_raw,
+                                   const float* scale_raw, const float* alpha_raw, const float* color_raw,
+                                   const float* quat, const float* base_color, const float* dist_ratio,
+                                   const int32_t* dest, const float* dL_dxyz, const float* dL_dscale,
+                                   const float* dL_drot, const float* dL_dalpha, const float* dL_dcolor,
+                                   const float* dL_dalpha_all, float* dL_dxyz_raw, float* dL_drot_raw,
+                                   float* dL_dscale_raw, float* dL_dalpha_raw, float* dL_dcolor_raw,
+                                   void* stream);
+
 #endif /* PINGS_HIP_H_ */

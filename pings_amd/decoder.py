@@ -6,8 +6,10 @@ independent).  `decoder` is the reference's `Decoder` object (or anything exposi
 `lout`, `use_leaky_relu`): its parameters are used in place, so optimiser steps and
 `state_dict()` behave as before.
 
-HIP tensors go through `pings_mlp_forward/backward` (csrc/mlp.hip); host tensors (CPU unit tests
-of the host logic) use the module's own torch layers.
+HIP tensors go through `pings_mlp_forward/backward` (csrc/mlp.hip).  Host tensors raise: there is no
+CPU path (the CPU restatement used by the tests is the decoder's own `mlp_batch`, called from oracle/).
+Decoder shapes the kernel does not cover (more than one hidden level, leaky ReLU, no bias — none of the
+shipped configs, pings.py:147-172) run the module's own layers on the device.
 """
 from __future__ import annotations
 
@@ -20,7 +22,12 @@ def _supported(decoder) -> bool:
 
 
 def mlp_batch(decoder, features: torch.Tensor) -> torch.Tensor:
-    if features.is_cuda and _supported(decoder):
+    if not features.is_cuda:
+        from . import _lib
+
+        raise _lib.PingsHipError("decoder.mlp_batch runs on the HIP device only (got a CPU tensor); "
+                                 "there is no CPU fallback")
+    if _supported(decoder):
         from . import mlp as _mlp
 
         l0, lo = decoder.layers[0], decoder.lout

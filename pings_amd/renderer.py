@@ -7,9 +7,9 @@ same `None` returns on empty views (:224,232,265,292,572), same ordering of the 
 GUI call it unchanged (INTEGRATION.md shows the two-line patch that routes them here).
 
 The rasteriser is pings_amd.rasterizer (HIP); the five decoder MLPs run through
-pings_amd.decoder.mlp_batch (HIP fused Linear-ReLU-Linear) when the tensors live on the HIP
-device; the element-wise activation / quaternion algebra in between is expressed in torch ops so
-autograd (including the mapper's double backward through the spawned Gaussians) keeps working.
+pings_amd.decoder.mlp_batch (HIP fused Linear-ReLU-Linear on the matrix cores) and everything around
+them — row gather, view features, activations, quaternion algebra, alpha / scale compaction — through
+pings_amd.spawn (csrc/spawn.hip).  There is no CPU path: host tensors raise.
 """
 from __future__ import annotations
 
@@ -18,37 +18,10 @@ from typing import Dict, Optional
 
 import torch
 
+from . import _lib
 from . import decoder as _dec
 from . import rasterizer as _rast
-
-
-# ------------------------------------------------------------------ quaternion helpers (utils/tools.py:743-844)
-def _rotate_passive(quat: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """R(q)^T v — what the reference's `apply_quaternion_rotation` computes (tools.py:743-751)."""
-    w = quat[..., :1]
-    u = -quat[..., 1:]
-    t = 2.0 * torch.linalg.cross(u, v)
-    return v + w * t + torch.linalg.cross(u, t)
-
-
-def _quat_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """Hamilton product a * b, [w,x,y,z] (tools.py:803-823)."""
-    w1, x1, y1, z1 = a.unbind(1)
-    w2, x2, y2, z2 = b.unbind(1)
-    return torch.stack((w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
-                        w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
-                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
-                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2), dim=1)
-
-
-def _quat_conj(q: torch.Tensor) -> torch.Tensor:
-    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
-
-
-def _per_gaussian(t: torch.Tensor, k: int) -> torch.Tensor:
-    """[N, d] -> [N*k, d]: every neural point's row repeated for its k Gaussians
-    (the reference's `.repeat(1, K).view(N*K, -1)`, :631,637)."""
-    return t.unsqueeze(1).expand(-1, k, -1).reshape(t.shape[0] * k, t.shape[1])
+from . import spawn as _spawn
 
 
 # ------------------------------------------------------------------ depth -> normal (point_utils.py:83-149)
@@ -99,13 +72,22 @@ def spawn_gaussians(neural_points_data: Dict,
                     scale_filter_ratio: float = 0.2,
                     record_shifted: bool = False,
                     ):
-    """Spawn K Gaussians per (visible, valid) neural point (gaussian_renderer/__init__.py:469-778)."""
+    """Spawn K Gaussians per (visible, valid) neural point (gaussian_renderer/__init__.py:469-778).
+
+    Device path: `spawn.gather` (rows of the mask -> MLP inputs incl. view features), five fused MLPs
+    (csrc/mlp.hip), `spawn.activate` (activations, quaternion algebra, alpha / scale compaction) — all HIP,
+    all differentiable w.r.t. the features and the decoder parameters."""
     d = neural_points_data
-    pos, quat = d["position"], d["orientation"]
-    base_color = d.get("color", None)
+    pos_all, quat_all = d["position"], d["orientation"]
+    if not pos_all.is_cuda:
+        raise _lib.PingsHipError("spawn_gaussians runs on the HIP device only (got CPU tensors); there is no CPU "
+                                 "fallback — the CPU restatement lives in oracle/spawn_cpu.py (tests only)")
+    if gs_type == "2d_gs":
+        raise NotImplementedError("gs_type='2d_gs' is outside the PINGS hot path (gaussian_renderer/__init__.py:350)")
+    base_all = d.get("color", None)
     geo_feat, col_feat = d["geo_feature"], d["color_feature"]
-    res = d["resolution"]
-    free = d.get("free_mask", None)
+    res = float(d["resolution"])
+    free_all = d.get("free_mask", None)
     valid = d.get("valid_mask", None)
 
     mask = None
@@ -116,105 +98,58 @@ def spawn_gaussians(neural_points_data: Dict,
     elif valid is not None:
         mask = valid
     if mask is not None:
-        sel = torch.nonzero(mask).view(-1)
-        pos, quat = pos[sel], quat[sel]
-        if base_color is not None:
-            base_color = base_color[sel]
-        if free is not None:
-            free = free[sel]
-        geo_in = geo_feat[sel]          # == features[cat(sel, -1)][:-1]  (:563-569,600)
-        col_in = col_feat[sel]
+        sel = torch.nonzero(mask).view(-1)      # features[cat(sel, -1)][:-1] == features[sel]  (:563-569,600)
+        n = int(sel.shape[0])
     else:
-        geo_in = geo_feat[:-1]
-        col_in = col_feat[:-1]
-
-    n = pos.shape[0]
-    if n < 10:                          # :572
+        sel = None
+        n = int(pos_all.shape[0])               # features[:-1]: the padding row is never read
+    if n < 10:                                  # :572
         return None
 
     m_xyz, m_scale, m_rot = decoders["gauss_xyz"], decoders["gauss_scale"], decoders["gauss_rot"]
     m_alpha, m_color = decoders["gauss_alpha"], decoders["gauss_color"]
     k = m_xyz.out_k
-    nk = n * k
 
-    view_dir = view_dist = None
-    if cam_origin is not None:
-        v = pos - cam_origin.float()
-        if view_direction_xy_only:      # horizontal direction / distance only (:592-597)
-            v = torch.cat((v[:, :-1], torch.zeros_like(v[:, -1:])), dim=1)
-        view_dist = v.norm(dim=1, keepdim=True)
-        view_dir = v / view_dist
+    have_cam = cam_origin is not None
+    geo_in, col_in, pos, quat, base, free, view_dist = _spawn.gather(
+        geo_feat, col_feat, sel, pos_all, quat_all, base_all, free_all, cam_origin, view_direction_xy_only,
+        view_concat_on and have_cam, dist_concat_on and have_cam)
+    # xyz / rot / scale read the plain geo feature; alpha additionally the view distance when dist_concat_on (:672-675)
+    geo_plain = geo_in[:, :geo_feat.shape[1]] if geo_in.shape[1] != geo_feat.shape[1] else geo_in
 
-    quat_g = _per_gaussian(quat, k)
+    xyz_raw = _dec.mlp_batch(m_xyz, geo_plain)
+    rot_raw = _dec.mlp_batch(m_rot, geo_plain)
+    scale_raw = _dec.mlp_batch(m_scale, geo_plain)
+    alpha_raw = _dec.mlp_batch(m_alpha, geo_in)
+    color_raw = _dec.mlp_batch(m_color, col_in)
 
-    # position: p + R(q)^T (range * tanh(mlp))                                     (:605-639)
-    disp = (displacement_range_ratio * res) * torch.tanh(_dec.mlp_batch(m_xyz, geo_in))
+    dist_ratio = (view_dist / z_far) if (have_cam and dist_adaptive_scale) else None
+    sp = _spawn.activate(xyz_raw, rot_raw, scale_raw, alpha_raw, color_raw, pos, quat,
+                         base if learn_color_residual else None, dist_ratio, free,
+                         n=n, k=k, surfel=(gs_type == "gaussian_surfel"),
+                         color_residual=bool(learn_color_residual and base is not None),
+                         alpha_filter_on=alpha_filter_on, scale_filter_on=scale_filter_on,
+                         displacement_range=displacement_range_ratio * res, unit_scale=unit_scale_ratio * res,
+                         max_scale=max_scale_ratio * res, scale_filter_thr=scale_filter_ratio * res)
+
     shifted_position = None
-    if record_shifted:
-        cand = disp.view(n, 3, k)
-        mag, arg = torch.max(torch.norm(cand, dim=1), dim=1)
-        pick = torch.gather(cand, 2, arg.view(-1, 1, 1).expand(-1, 3, 1)).squeeze(2)
-        far = mag > 2.0 * res
-        shifted_position = pos[far] + pick[far]
-    gaussian_xyz = _per_gaussian(pos, k) + _rotate_passive(quat_g, disp.reshape(nk, 3))
-
-    # rotation: q_point * normalize(mlp)                                             (:644-649)
-    r = torch.nn.functional.normalize(_dec.mlp_batch(m_rot, geo_in).reshape(nk, 4))
-    gaussian_rot = _quat_mul(quat_g, torch.nan_to_num(r, 0, 0))
-
-    # scale: min(unit * res * exp(mlp [+ dist/z_far]), max * res)                    (:655-670)
-    s_arg = _dec.mlp_batch(m_scale, geo_in)
-    if view_dist is not None and dist_adaptive_scale:
-        s_arg = s_arg + (view_dist / z_far).repeat(1, m_scale.mlp_out_dim)
-    s = torch.clamp(unit_scale_ratio * res * torch.exp(s_arg), max=max_scale_ratio * res).reshape(nk, -1)
-    if gs_type == "gaussian_surfel":
-        gaussian_scale = torch.cat((s[:, :2], torch.full((nk, 1), 1e-7, dtype=s.dtype, device=s.device)), dim=1)
-    elif gs_type == "2d_gs":
-        gaussian_scale = s[:, :2]
-    else:
-        gaussian_scale = s
-
-    # opacity: tanh(mlp(geo [, dist]))  (<= 0 means "not spawned")                   (:677-687)
-    a_in = torch.cat((geo_in, view_dist), dim=1) if (dist_concat_on and view_dist is not None) else geo_in
-    gaussian_alpha = torch.tanh(_dec.mlp_batch(m_alpha, a_in)).reshape(nk, 1)
-
-    # colour                                                                          (:692-716)
-    c_in = col_in
-    if view_concat_on and view_dir is not None:
-        c_in = torch.cat((c_in, _rotate_passive(_quat_conj(quat), view_dir)), dim=1)
-    c_out = _dec.mlp_batch(m_color, c_in)
-    if learn_color_residual and base_color is not None:
-        gaussian_color = torch.clamp(base_color.repeat(1, k) + 0.1 * torch.tanh(c_out), 0.0, 1.0)
-    else:
-        gaussian_color = torch.sigmoid(c_out)
-    gaussian_color = gaussian_color.reshape(nk, 3)
-
-    alpha_all = gaussian_alpha.clone()
-    # NB: the reference tiles the 1-D per-point mask ([N].repeat(1, K).view(-1), :724), i.e. Gaussian j
-    # gets free[j % N], not free[j // K]; kept as is for drop-in parity.
-    gaussian_free_mask = free.repeat(k) if free is not None else None
-
-    def keep(m):
-        nonlocal gaussian_xyz, gaussian_scale, gaussian_rot, gaussian_alpha, gaussian_color, gaussian_free_mask
-        gaussian_xyz, gaussian_scale, gaussian_rot = gaussian_xyz[m], gaussian_scale[m], gaussian_rot[m]
-        gaussian_alpha, gaussian_color = gaussian_alpha[m], gaussian_color[m]
-        if gaussian_free_mask is not None:
-            gaussian_free_mask = gaussian_free_mask[m]
-
-    if alpha_filter_on:                 # :727-740
-        keep(gaussian_alpha.squeeze(-1) > 0.0)
-    if scale_filter_on:                 # :747-761
-        keep(torch.any(gaussian_scale > scale_filter_ratio * res, dim=1))
+    if record_shifted:                          # deprecated in the reference (:617-627); rare, left to torch
+        with torch.no_grad():
+            cand = ((displacement_range_ratio * res) * torch.tanh(xyz_raw)).view(n, 3, k)
+            mag, arg = torch.max(torch.norm(cand, dim=1), dim=1)
+            pick = torch.gather(cand, 2, arg.view(-1, 1, 1).expand(-1, 3, 1)).squeeze(2)
+            far = mag > 2.0 * res
+            shifted_position = pos[far] + pick[far]
 
     return {
-        "gaussian_xyz": gaussian_xyz,
-        "gaussian_scale": gaussian_scale,
-        "gaussian_rot": gaussian_rot,
-        "gaussian_alpha": gaussian_alpha,
-        "gaussian_color": gaussian_color,
-        "alpha_all": alpha_all,
-        "gaussian_free_mask": gaussian_free_mask,
-        "local_view_gaussian_count": gaussian_xyz.shape[0],
+        "gaussian_xyz": sp.xyz,
+        "gaussian_scale": sp.scale,
+        "gaussian_rot": sp.rot,
+        "gaussian_alpha": sp.alpha,
+        "gaussian_color": sp.color,
+        "alpha_all": sp.alpha_all,
+        "gaussian_free_mask": sp.free_mask,
+        "local_view_gaussian_count": sp.count,
         "shifted_position": shifted_position,
     }
 

@@ -1,4 +1,6 @@
-"""spawn_gaussians / render glue: host logic vs the reference's golden vectors (CPU and GPU)."""
+"""spawn_gaussians: the CPU oracle (oracle/spawn_cpu.py) is pinned by the reference's golden vectors (G4);
+the HIP path (pings_amd.renderer.spawn_gaussians -> csrc/spawn.hip, csrc/mlp.hip) is checked against the same
+vectors and, on larger random inputs and every option, against the oracle."""
 from types import SimpleNamespace as NS
 
 import numpy as np
@@ -32,7 +34,10 @@ class Dec(torch.nn.Module):
 
 
 def _run(st, device):
-    from pings_amd.renderer import spawn_gaussians
+    if device == "cpu":
+        from oracle.spawn_cpu import spawn_gaussians
+    else:
+        from pings_amd.renderer import spawn_gaussians
 
     T = lambda k: torch.from_numpy(st[k]).to(device)
     K = int(st["K"])
@@ -72,14 +77,28 @@ def _check(st, res, loss, grads, decs, tol):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_spawn_host_logic_matches_reference_golden_cpu(golden_dir, name):
+def test_spawn_oracle_matches_reference_golden_cpu(golden_dir, name):
     z = np.load(golden_dir / f"spawn_{name}.npz")
     st = {k: z[k] for k in z.files}
     _check(st, *_run(st, "cpu"), tol=1e-5)
 
 
-def test_spawn_returns_none_below_ten_points(golden_dir):
+def test_spawn_product_path_rejects_host_tensors(golden_dir):
+    from pings_amd import _lib
     from pings_amd.renderer import spawn_gaussians
+
+    z = np.load(golden_dir / "spawn_surfel_direct.npz")
+    st = {k: z[k] for k in z.files}
+    T = lambda k: torch.from_numpy(st[k])
+    decs = {n: Dec(st, n, int(st["K"]), "cpu") for n in DEC}
+    data = {"position": T("position"), "orientation": T("orientation"), "geo_feature": T("geo_feature"),
+            "color_feature": T("color_feature"), "resolution": 0.25}
+    with pytest.raises(_lib.PingsHipError):
+        spawn_gaussians(data, decs, None, T("cam_origin"), gs_type="gaussian_surfel")
+
+
+def test_spawn_oracle_returns_none_below_ten_points(golden_dir):
+    from oracle.spawn_cpu import spawn_gaussians
 
     z = np.load(golden_dir / "spawn_surfel_direct.npz")
     st = {k: z[k] for k in z.files}
@@ -96,3 +115,77 @@ def test_spawn_matches_reference_golden_hip(golden_dir, name):
     z = np.load(golden_dir / f"spawn_{name}.npz")
     st = {k: z[k] for k in z.files}
     _check(st, *_run(st, "cuda"), tol=1e-4)   # tolerance: north_star 1e-4 rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [
+    dict(gs_type="gaussian_surfel", view_concat_on=True, learn_color_residual=True),
+    dict(gs_type="gaussian_surfel", view_concat_on=False, learn_color_residual=False, scale_filter_on=True),
+    dict(gs_type="gaussian_surfel", view_concat_on=True, dist_concat_on=True, dist_adaptive_scale=True,
+         alpha_filter_on=False),
+    dict(gs_type="3d_gs", view_concat_on=True, learn_color_residual=True, view_direction_xy_only=False,
+         scale_filter_on=True, record_shifted=True),
+    dict(gs_type="gaussian_surfel", no_mask=True, no_cam=True),
+])
+def test_spawn_hip_matches_oracle_random(opts):
+    """20k neural points (5k visible), K = 8, F = 32/16, hidden 128, non-identity orientations: outputs, compaction
+    and every gradient of the HIP path vs the fp64 CPU oracle (tolerance 1e-4 rel, north_star)."""
+    from oracle.spawn_cpu import spawn_gaussians as ref_spawn
+    from pings_amd.renderer import spawn_gaussians as hip_spawn
+
+    opts = dict(opts)
+    no_mask, no_cam = opts.pop("no_mask", False), opts.pop("no_cam", False)
+    g = torch.Generator().manual_seed(11)
+    N, K, Fg, Fc, HID = 20000, 8, 32, 16, 128
+    view_c = opts.get("view_concat_on", False) and not no_cam
+    dist_c = opts.get("dist_concat_on", False) and not no_cam
+    st = {}
+    for name, fin, out in [("gauss_xyz", Fg, 3), ("gauss_rot", Fg, 4), ("gauss_scale", Fg, 3),
+                           ("gauss_alpha", Fg + int(dist_c), 1), ("gauss_color", Fc + 3 * int(view_c), 3)]:
+        st[f"dec.{name}.layers.0.weight"] = (torch.randn(HID, fin, generator=g) / fin ** 0.5).numpy()
+        st[f"dec.{name}.layers.0.bias"] = (0.1 * torch.randn(HID, generator=g)).numpy()
+        st[f"dec.{name}.lout.weight"] = (torch.randn(out * K, HID, generator=g) / HID ** 0.5).numpy()
+        st[f"dec.{name}.lout.bias"] = (0.1 * torch.randn(out * K, generator=g)).numpy()
+    pos = (torch.rand(N, 3, generator=g) - 0.5) * 40
+    quat = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1)
+    col = torch.rand(N, 3, generator=g)
+    geo = 0.7 * torch.randn(N + 1, Fg, generator=g)
+    cfe = 0.7 * torch.randn(N + 1, Fc, generator=g)
+    vis = torch.rand(N, generator=g) < 0.27
+    valid = torch.rand(N, generator=g) < 0.95
+    free = torch.rand(N, generator=g) < 0.1
+    cam = torch.tensor([1.0, -2.0, 0.5])
+
+    def run(device, dtype, fn):
+        decs = {n: Dec(st, n, K, device).to(dtype) for n in DEC}
+        ge = geo.to(device=device, dtype=dtype).requires_grad_(True)
+        ce = cfe.to(device=device, dtype=dtype).requires_grad_(True)
+        data = {"position": pos.to(device, dtype), "orientation": quat.to(device, dtype), "color": col.to(device, dtype),
+                "geo_feature": ge, "color_feature": ce, "resolution": 0.3, "free_mask": free.to(device)}
+        if not no_mask:
+            data["valid_mask"] = valid.to(device)
+        res = fn(data, decs, None if no_mask else vis.to(device), None if no_cam else cam.to(device, dtype),
+                 z_far=80.0, displacement_range_ratio=2.0, max_scale_ratio=1.0, unit_scale_ratio=0.4,
+                 scale_filter_ratio=0.45, **opts)
+        keys = ["gaussian_xyz", "gaussian_scale", "gaussian_rot", "gaussian_alpha", "gaussian_color", "alpha_all"]
+        gw = torch.Generator().manual_seed(5)
+        loss = 0
+        for kk in keys:
+            w = torch.randn(res[kk].shape, generator=gw).to(device=device, dtype=dtype)
+            loss = loss + (res[kk] * w).sum()
+        params = [p for n in DEC for p in decs[n].parameters()]
+        grads = torch.autograd.grad(loss, [ge, ce] + params)
+        return res, grads, keys
+
+    r_ref, g_ref, keys = run("cpu", torch.float64, ref_spawn)
+    r_hip, g_hip, _ = run("cuda", torch.float32, hip_spawn)
+    assert r_hip["local_view_gaussian_count"] == r_ref["local_view_gaussian_count"]
+    assert torch.equal(r_hip["gaussian_free_mask"].cpu(), r_ref["gaussian_free_mask"])
+    for kk in keys:
+        assert r_hip[kk].shape == r_ref[kk].shape, kk
+        assert rel_err(r_hip[kk], r_ref[kk]) <= 1e-4, kk
+    if opts.get("record_shifted"):
+        assert r_hip["shifted_position"].shape == r_ref["shifted_position"].shape
+        assert rel_err(r_hip["shifted_position"], r_ref["shifted_position"]) <= 1e-4
+    for a, b in zip(g_hip, g_ref):
+        assert rel_err(a, b) <= 1e-4
