@@ -107,14 +107,19 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
   __shared__ uint32_t sRow[BATCH];  // compact gradient-row index, DEAD_ROW for dead instances
   __shared__ float4 sG[NWV][BATCH][4];
   __shared__ uint32_t sMax;
+  __shared__ uint8_t sList[NWV][BATCH];  // per-wave list of live records that may reach its pixels (ascending)
+  __shared__ int sNum[NWV];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int tx = tile % p.gx, ty = tile / p.gx;
-  const int pix_x = tx * TILE + (lane & (TILE - 1));
-  const int pix_y0 = ty * TILE + wave * 4 * PPL + (lane >> 4);
+  // lane -> pixel map and per-wave culled record lists as in blend_fwd_kernel (8x8 quadrants)
+  constexpr int YS = 8;
+  const int pix_x = tx * TILE + (PPL == 1 ? 8 * (wave & 1) : 8 * wave) + (lane & 7);
+  const int pix_y0 = ty * TILE + (PPL == 1 ? 8 * (wave >> 1) : 0) + (lane >> 3);
   const float pixf_x = (float)pix_x, pixf_y0 = (float)pix_y0;
+  const float tileX0 = (float)(tx * TILE), tileY0 = (float)(ty * TILE);
   const size_t HW = (size_t)p.W * p.H;
 
   float rx = 0.f, ry[PPL];
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
     rx = (pixf_x - cxp) / p.fx;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(4 * k)) - cyp) / p.fy;
+    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(YS * k)) - cyp) / p.fy;
   }
 
   const uint2 range = ranges[tile];
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     T[k] = 1.f;
     gC0[k] = gC1[k] = gC2[k] = gN0[k] = gN1[k] = gN2[k] = gD[k] = coefT[k] = 0.f;
     B0[k] = B1[k] = B2[k] = BN0[k] = BN1[k] = BN2[k] = BD[k] = 0.f;
-    const int pix_y = pix_y0 + 4 * k;
+    const int pix_y = pix_y0 + YS * k;
     if (pix_x < p.W && pix_y < p.H) {
       const size_t pix_id = (size_t)pix_y * p.W + pix_x;
       last[k] = n_contrib[pix_id];
@@ -188,16 +193,33 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     const int start = b * BATCH;
     const int n = min(BATCH, max_last - start);
     __syncthreads();  // previous batch's LDS fully consumed
-    if (tid < n) {
-      const uint32_t g = point_list[range.x + start + tid];
-      sA[tid] = rec[4 * (size_t)g + 0];
-      sB[tid] = rec[4 * (size_t)g + 1];
-      sC[tid] = rec[4 * (size_t)g + 2];
-      if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
-      const uint4 rc = rect[g];
-      const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
-      const uint32_t slot = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
-      sRow[tid] = inst_w[slot] > 0.f ? cidx[slot] : DEAD_ROW;
+    if (wave == 0) {  // BATCH == 64: the first wave stages the batch and builds every wave's list
+      uint32_t qm = 0;
+      if (tid < n) {
+        const uint32_t g = point_list[range.x + start + tid];
+        const float4 ra = rec[4 * (size_t)g + 0];
+        const float4 rb = rec[4 * (size_t)g + 1];
+        sA[tid] = ra;
+        sB[tid] = rb;
+        sC[tid] = rec[4 * (size_t)g + 2];
+        if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
+        const uint4 rc = rect[g];
+        const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
+        const uint32_t slot = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+        const bool live = inst_w[slot] > 0.f;  // blended something in the forward pass
+        sRow[tid] = live ? cidx[slot] : DEAD_ROW;
+        if (live) qm = quadrant_mask(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, tileX0, tileY0);
+      }
+#pragma unroll
+      for (int wv = 0; wv < NWV; ++wv) {
+        const uint32_t need = PPL == 1 ? (1u << wv) : ((1u << wv) | (4u << wv));
+        const bool hit = (qm & need) != 0;
+        const unsigned long long bal = __ballot(hit);
+        if (hit)
+          sList[wv][__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+              (uint8_t)tid;
+        if (lane == 0) sNum[wv] = __popcll(bal);
+      }
     }
     {
       float4* z = &sG[0][0][0];
@@ -208,16 +230,19 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
 
     // Record j-1 is read from LDS while j is processed; per-lane conditions are selects, the only
     // branches are workgroup- or wave-uniform.
-    float4 a = sA[n - 1], bq = sB[n - 1], c = sC[n - 1], nn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == MODE_SURFEL) nn = sD[n - 1];
-    for (int j = n - 1; j >= 0; --j) {
-      const int jn = j > 0 ? j - 1 : 0;
+    const int cnt = sNum[wave];
+    int jcur = cnt > 0 ? (int)sList[wave][cnt - 1] : 0;
+    float4 a = sA[jcur], bq = sB[jcur], c = sC[jcur], nn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == MODE_SURFEL) nn = sD[jcur];
+    for (int jj = cnt - 1; jj >= 0; --jj) {
+      const int j = jcur;
+      const int jn = (int)sList[wave][jj > 0 ? jj - 1 : 0];
       const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
       float4 n_n = nn;
       if (MODE == MODE_SURFEL) n_n = sD[jn];
       const float4 ca = a, cb = bq, cc = c, cn = nn;
       a = a_n; bq = b_n; c = c_n; nn = n_n;
-      if (sRow[j] == DEAD_ROW) continue;  // blended nothing in the forward pass (workgroup-uniform)
+      jcur = jn;
       const uint32_t idx = (uint32_t)(start + j);
       const float dx = ca.x - pixf_x;
       const float p0 = -0.5f * (cb.x * dx * dx);
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
       bool any_v = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const float dy = ca.y - (pixf_y0 + (float)(4 * k));
+        const float dy = ca.y - (pixf_y0 + (float)(YS * k));
         dyv[k] = dy;
         const float power = (p0 - 0.5f * (cb.z * dy * dy)) - pxy * dy;
         Gs[k] = __expf(power);
@@ -732,11 +757,9 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
                      dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx, bw.rows)
     if (s->mode == PINGS_RASTER_SURFEL) {
       if (ppl == 1) PINGS_BLEND_BWD(MODE_SURFEL, 1);
-      else if (ppl == 4) PINGS_BLEND_BWD(MODE_SURFEL, 4);
       else PINGS_BLEND_BWD(MODE_SURFEL, 2);
     } else {
       if (ppl == 1) PINGS_BLEND_BWD(MODE_3DGS, 1);
-      else if (ppl == 4) PINGS_BLEND_BWD(MODE_3DGS, 4);
       else PINGS_BLEND_BWD(MODE_3DGS, 2);
     }
 #undef PINGS_BLEND_BWD

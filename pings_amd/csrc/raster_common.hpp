@@ -116,5 +116,44 @@ __device__ inline float wave_sum_to_all(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---------------------------------------------------------------- sub-tile culling
+// A record contributes to a pixel only if alpha = min(0.99, o exp(power)) >= 1/255, i.e.
+// q(d) = cx dx^2 + 2 cy dx dy + cz dy^2 <= 2 ln(255 o).  `footprint_misses_rect` is true when the smallest q over
+// a closed pixel rectangle exceeds that bound by more than the fp32 error the blend kernels' own evaluation of
+// `power` can have (the terms cancel for large anisotropic footprints, so the margin scales with their
+// magnitude): no pixel of the rectangle can pass the alpha test, and skipping the record for the wave that owns
+// the rectangle leaves every output bit unchanged.
+__device__ inline float edge_min_q(float a, float b, float c, float d_fixed, float lo, float hi) {
+  // q along the edge {fixed offset d_fixed on one axis, free offset t in [lo, hi] on the other}:
+  //   q(t) = a d^2 + 2 b d t + c t^2, minimised at t* = -b d / c, clamped to the edge
+  const float t = fminf(fmaxf(-(b * d_fixed) / c, lo), hi);
+  const float q0 = a * d_fixed * d_fixed, q1 = 2.f * b * d_fixed * t, q2 = c * t * t;
+  return (q0 + q1 + q2) - 2e-5f * (q0 + fabsf(q1) + q2);
+}
+
+__device__ inline bool footprint_misses_rect(float mx, float my, float cx, float cy, float cz, float thr,
+                                             float x0, float x1, float y0, float y1) {
+  if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return false;  // centre inside: q = 0
+  const float lx = x0 - mx, hx = x1 - mx, ly = y0 - my, hy = y1 - my;
+  float m = edge_min_q(cx, cy, cz, lx, ly, hy);             // edge x = x0
+  m = fminf(m, edge_min_q(cx, cy, cz, hx, ly, hy));         // edge x = x1
+  m = fminf(m, edge_min_q(cz, cy, cx, ly, lx, hx));         // edge y = y0
+  m = fminf(m, edge_min_q(cz, cy, cx, hy, lx, hx));         // edge y = y1
+  return m > thr;                                           // NaN -> false (keep)
+}
+
+// Bit q = 1 iff the record may touch the 8x8 pixel quadrant q = (qx + 2 qy) of the 16x16 tile at (X0, Y0).
+__device__ inline uint32_t quadrant_mask(float mx, float my, float opacity, float cx, float cy, float cz,
+                                         float X0, float Y0) {
+  const float thr = 2.f * __logf(255.f * opacity) + 2e-3f;
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = X0 + (float)(8 * (q & 1)), y0 = Y0 + (float)(8 * (q >> 1));
+    if (!footprint_misses_rect(mx, my, cx, cy, cz, thr, x0, x0 + 7.f, y0, y0 + 7.f)) m |= 1u << q;
+  }
+  return m;
+}
+
 }  // namespace raster
 }  // namespace pings

@@ -315,10 +315,21 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const KeyT*
   if (i == I - 1 || key[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
-// PPL = pixels per lane (1, 2 or 4).  A 16x16 tile is covered by 4/PPL waves; lane (x = lane&15,
-// yb = lane>>4) of wave w owns the PPL pixels (x, 4*PPL*w + 4k + yb), k < PPL, which share x: the
-// x-part of the quadratic form, the record unpacking, the loop control and the wave reductions are
-// paid once per lane instead of once per pixel.
+#ifdef PINGS_BLEND_STATS  // diagnostic build only (scratch/): loop-efficiency counters of blend_fwd_kernel
+__device__ unsigned long long g_blend_stats[8];
+#endif
+
+// PPL = pixels per lane (1 or 2).  A 16x16 tile is four 8x8 quadrants.  PPL = 1: wave w owns quadrant w
+// (qx = w & 1, qy = w >> 1), lane l the pixel (l & 7, l >> 3) of it.  PPL = 2: wave w owns the 8-pixel-wide
+// column half w (quadrants w and w + 2), lane l the two pixels (l & 7, l >> 3) and (l & 7, (l >> 3) + 8), which
+// share x: the x-part of the quadratic form, the record unpacking, the loop control and the wave reductions
+// are paid once per lane instead of once per pixel.
+//
+// Sub-tile culling: while a round of up to 256 records is staged in LDS, the staging thread of a record also
+// evaluates which quadrants its footprint ellipse (alpha >= 1/255) can reach (quadrant_mask).  Every wave then
+// compacts the records that may touch ITS pixels into a private index list (ballot + popcount, order kept) and
+// walks only that list: on surfel scenes 40-50 % of the (wave, record) visits of a plain tile walk blend
+// nothing, and a skipped record would have contributed exactly zero, so outputs are unchanged bit for bit.
 template <int MODE, int PPL>
 __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     uint32_t* __restrict__ inst_cnt) {
   constexpr int NT = BLOCK / PPL;   // threads per workgroup
   constexpr int NWV = NT / 64;      // waves per workgroup
+  constexpr int YS = 8;             // row distance of a lane's pixels
   __shared__ float4 sA[BLOCK];  // mx, my, opacity, pz
   __shared__ float4 sB[BLOCK];  // conic, rz
   __shared__ float4 sC[BLOCK];  // rgb, q
@@ -335,14 +347,18 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
   __shared__ uint32_t sSlot[BLOCK];
   __shared__ float sAcc[NWV][BLOCK];     // per-wave partial sums of blend weights
   __shared__ uint32_t sCnt[NWV][BLOCK];  // per-wave counts (3DGS n_touched)
+  __shared__ uint8_t sMask[BLOCK];       // quadrant mask of every staged record
+  __shared__ uint8_t sList[NWV][BLOCK];  // per-wave compacted record indices (ascending)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int tx = tile % p.gx, ty = tile / p.gx;
-  const int pix_x = tx * TILE + (lane & (TILE - 1));
-  const int pix_y0 = ty * TILE + wave * 4 * PPL + (lane >> 4);
+  const int pix_x = tx * TILE + (PPL == 1 ? 8 * (wave & 1) : 8 * wave) + (lane & 7);
+  const int pix_y0 = ty * TILE + (PPL == 1 ? 8 * (wave >> 1) : 0) + (lane >> 3);
+  const uint32_t need = PPL == 1 ? (1u << wave) : ((1u << wave) | (4u << wave));
   const float pixf_x = (float)pix_x, pixf_y0 = (float)pix_y0;
+  const float tileX0 = (float)(tx * TILE), tileY0 = (float)(ty * TILE);
   const size_t HW = (size_t)p.W * p.H;
 
   float rx = 0.f, ry[PPL];
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
     rx = (pixf_x - cxp) / p.fx;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(4 * k)) - cyp) / p.fy;
+    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(YS * k)) - cyp) / p.fy;
   }
 
   const uint2 range = ranges[tile];
@@ -368,26 +384,35 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     T[k] = 1.0f;
     C0[k] = C1[k] = C2[k] = N0[k] = N1[k] = N2[k] = D[k] = 0.f;
     last[k] = 0;
-    inside[k] = pix_x < p.W && (pix_y0 + 4 * k) < p.H;
+    inside[k] = pix_x < p.W && (pix_y0 + YS * k) < p.H;
     done[k] = !inside[k];
     all_done = all_done && done[k];
   }
 
+#ifdef PINGS_BLEND_STATS
+  unsigned long long st_iter = 0, st_any = 0, st_lanes = 0, st_staged = 0, st_livepix = 0;
+#endif
   for (int base = 0; base < todo; base += BLOCK) {
     if (__syncthreads_and(all_done)) break;
     const int n = min(BLOCK, todo - base);
+#ifdef PINGS_BLEND_STATS
+    st_staged += (unsigned long long)n;
+#endif
 #pragma unroll
     for (int rr = 0; rr < PPL; ++rr) {
       const int e = tid + rr * NT;
       if (e < n) {
         const uint32_t g = point_list[range.x + base + e];
-        sA[e] = rec[4 * (size_t)g + 0];
-        sB[e] = rec[4 * (size_t)g + 1];
+        const float4 ra = rec[4 * (size_t)g + 0];
+        const float4 rb = rec[4 * (size_t)g + 1];
+        sA[e] = ra;
+        sB[e] = rb;
         sC[e] = rec[4 * (size_t)g + 2];
         if (MODE == MODE_SURFEL) sD[e] = rec[4 * (size_t)g + 3];
         const uint4 rc = rect[g];
         const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
         sSlot[e] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+        sMask[e] = (uint8_t)quadrant_mask(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, tileX0, tileY0);
 #pragma unroll
         for (int wv = 0; wv < NWV; ++wv) {
           sAcc[wv][e] = 0.f;
@@ -397,12 +422,24 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     }
     __syncthreads();
 
-    // The record of Gaussian j+1 is read from LDS while j is blended; lanes that skip a Gaussian carry
+    // this wave's list: records whose footprint may reach its pixels, in list order
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int e = c0 + lane;
+      const bool hit = e < n && (sMask[e] & need) != 0;
+      const unsigned long long bal = __ballot(hit);
+      if (hit) sList[wave][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)e;
+      cnt += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // The record of list entry jj+1 is read from LDS while jj is blended; lanes that skip a Gaussian carry
     // w = 0 and the only branches are wave-uniform.
-    float4 a = sA[0], b = sB[0], c = sC[0], nn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == MODE_SURFEL) nn = sD[0];
-    for (int j = 0; j < n; ++j) {
-      const int jn = j + 1 < n ? j + 1 : j;
+    int j = cnt > 0 ? (int)sList[wave][0] : 0;
+    float4 a = sA[j], b = sB[j], c = sC[j], nn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == MODE_SURFEL) nn = sD[j];
+    for (int jj = 0; jj < cnt; ++jj) {
+      const int jn = (int)sList[wave][jj + 1 < cnt ? jj + 1 : jj];
       const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
       float4 n_n = nn;
       if (MODE == MODE_SURFEL) n_n = sD[jn];
@@ -416,7 +453,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
       bool any_c = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const float dy = a.y - (pixf_y0 + (float)(4 * k));  // one rounding, as in the oracle
+        const float dy = a.y - (pixf_y0 + (float)(YS * k));  // one rounding, as in the oracle
         const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
         alpha[k] = fminf(ALPHA_MAX, a.z * __expf(power));
         const bool valid = !done[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
@@ -426,10 +463,19 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
         done[k] = done[k] || stop;
         any_c = any_c || contrib[k];
       }
+#ifdef PINGS_BLEND_STATS
+      st_iter += 1;
+      st_any += __any(any_c) ? 1 : 0;
+      st_lanes += (unsigned long long)__popcll(__ballot(any_c));
+      {
+        bool lv = false;
+        for (int k = 0; k < PPL; ++k) lv = lv || !done[k];
+        st_livepix += (unsigned long long)__popcll(__ballot(lv));
+      }
+#endif
       if (__any(any_c)) {
         float wsum = 0.f;
         uint32_t touched = 0;
-        const float dbase = (MODE == MODE_SURFEL) ? (nn.x * rx + nn.z) : 0.f;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
           const float w = contrib[k] ? alpha[k] * T[k] : 0.f;
@@ -439,7 +485,6 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
           C2[k] = fmaf(c.z, w, C2[k]);
           if (MODE == MODE_SURFEL) {
             const float den = (nn.x * rx + nn.y * ry[k]) + nn.z;
-            (void)dbase;
             float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
             d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
             N0[k] = fmaf(nn.x, w, N0[k]);
@@ -456,14 +501,15 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
         const float s = wave_reduce_sum_dpp(wsum);
         if (lane == 63) sAcc[wave][j] = s;
         if (MODE == MODE_3DGS) {
-          const uint32_t cnt = wave_reduce_sum_u32_dpp(touched);
-          if (lane == 63) sCnt[wave][j] = cnt;
+          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
+          if (lane == 63) sCnt[wave][j] = cn;
         }
       }
       all_done = true;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) all_done = all_done && done[k];
       a = a_n; b = b_n; c = c_n; nn = n_n;
+      j = jn;
     }
     __syncthreads();
 #pragma unroll
@@ -471,24 +517,33 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
       const int e = tid + rr * NT;
       if (e < n) {
         float v = sAcc[0][e];
-        uint32_t cnt = (MODE == MODE_3DGS) ? sCnt[0][e] : 0u;
+        uint32_t cn = (MODE == MODE_3DGS) ? sCnt[0][e] : 0u;
 #pragma unroll
         for (int wv = 1; wv < NWV; ++wv) {
           v += sAcc[wv][e];
-          if (MODE == MODE_3DGS) cnt += sCnt[wv][e];
+          if (MODE == MODE_3DGS) cn += sCnt[wv][e];
         }
         if (v != 0.f) {  // untouched slots stay at their memset zero
           inst_w[sSlot[e]] = v;
-          if (MODE == MODE_3DGS) inst_cnt[sSlot[e]] = cnt;
+          if (MODE == MODE_3DGS) inst_cnt[sSlot[e]] = cn;
         }
       }
     }
   }
 
+#ifdef PINGS_BLEND_STATS
+  if (lane == 0) {
+    atomicAdd(&g_blend_stats[0], st_iter);
+    atomicAdd(&g_blend_stats[1], st_any);
+    atomicAdd(&g_blend_stats[2], st_lanes);
+    atomicAdd(&g_blend_stats[4], st_livepix);
+    if (wave == 0) atomicAdd(&g_blend_stats[3], st_staged);
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     if (!inside[k]) continue;
-    const size_t pix_id = (size_t)(pix_y0 + 4 * k) * p.W + pix_x;
+    const size_t pix_id = (size_t)(pix_y0 + YS * k) * p.W + pix_x;
     const float A = 1.0f - T[k];
     final_T[pix_id] = T[k];
     n_contrib[pix_id] = last[k];
@@ -739,11 +794,9 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                      im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt)
   if (s->mode == PINGS_RASTER_SURFEL) {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
-    else if (ppl == 4) PINGS_BLEND_FWD(MODE_SURFEL, 4);
     else PINGS_BLEND_FWD(MODE_SURFEL, 2);
   } else {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_3DGS, 1);
-    else if (ppl == 4) PINGS_BLEND_FWD(MODE_3DGS, 4);
     else PINGS_BLEND_FWD(MODE_3DGS, 2);
   }
 #undef PINGS_BLEND_FWD
@@ -767,6 +820,18 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   }
   return PINGS_OK;
 }
+
+#ifdef PINGS_BLEND_STATS
+PINGS_API int pings_debug_blend_stats(unsigned long long* out8, int reset) {
+  PINGS_HIP_CHECK(hipDeviceSynchronize());
+  PINGS_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pings::raster::g_blend_stats), 64));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    PINGS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pings::raster::g_blend_stats), z, 64));
+  }
+  return PINGS_OK;
+}
+#endif
 
 PINGS_API int pings_raster_debug_lists(const void* binning_blob, int64_t I, int image_height,
                                        int image_width, uint32_t* point_list, uint32_t* ranges_xy,
