@@ -106,14 +106,17 @@ PINGS_API int pings_raster_mark_visible(const float* positions, int N,
                                         const pings_raster_settings* s, uint8_t* present,
                                         void* stream);
 
-PINGS_API size_t pings_raster_geom_bytes(int P);
+PINGS_API size_t pings_raster_geom_bytes(int P, int image_height, int image_width);
 PINGS_API size_t pings_raster_binning_bytes(int64_t num_instances, int image_height,
                                             int image_width);
 PINGS_API size_t pings_raster_image_bytes(int image_height, int image_width);
 
-/* Stage 1: per-Gaussian projection, culling, depth sort and tile counting.
+/* Stage 1: per-Gaussian projection, culling, depth sort, occlusion bound and tile counting.
  * Writes radii[P] (int32, 0 = culled) and *num_instances (HOST int64: number of
- * (Gaussian, tile) pairs).  Synchronises `stream` once to return that count. */
+ * (Gaussian, tile) pairs that can still reach a pixel: pairs behind the depth rank at which a
+ * conservative bound proves every pixel of the tile saturated are never created; set
+ * PINGS_RASTER_OCCLUSION=0 in the environment to keep them all).  Synchronises `stream` once to
+ * return that count. */
 PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, const float* means3D,
                                       const float* colors, const float* opacities,
                                       const float* scales, const float* rotations,

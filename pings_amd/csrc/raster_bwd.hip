@@ -95,7 +95,7 @@ __device__ inline float wave_reduce16(const float (&v)[16], int lane) {
 template <int MODE, int PPL>
 __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ rec, const uint4* __restrict__ rect,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth,
@@ -196,16 +196,14 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
     if (wave == 0) {  // BATCH == 64: the first wave stages the batch and builds every wave's list
       uint32_t qm = 0;
       if (tid < n) {
-        const uint32_t g = point_list[range.x + start + tid];
+        const uint32_t slot = point_list[range.x + start + tid];
+        const uint32_t g = gval[slot];
         const float4 ra = rec[4 * (size_t)g + 0];
         const float4 rb = rec[4 * (size_t)g + 1];
         sA[tid] = ra;
         sB[tid] = rb;
         sC[tid] = rec[4 * (size_t)g + 2];
         if (MODE == MODE_SURFEL) sD[tid] = rec[4 * (size_t)g + 3];
-        const uint4 rc = rect[g];
-        const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
-        const uint32_t slot = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
         const bool live = inst_w[slot] > 0.f;  // blended something in the forward pass
         sRow[tid] = live ? cidx[slot] : DEAD_ROW;
         if (live) qm = quadrant_mask(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, tileX0, tileY0);
@@ -723,7 +721,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   bp.bg = s->bg;
   bp.prcp = s->prcppoint;
   const int num_tiles = bp.gx * bp.gy;
-  GeomState gs = carve_geom(const_cast<void*>(geom_blob), P);
+  GeomState gs = carve_geom(const_cast<void*>(geom_blob), P, num_tiles);
   BinState bs = carve_binning(const_cast<void*>(binning_blob), I, num_tiles);
   ImageState im = carve_image(const_cast<void*>(image_blob), bp.W, bp.H);
   BwdState bw = carve_bwd(bwd_blob, P, I);
@@ -753,7 +751,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
     if (const char* e = getenv("PINGS_BLEND_BWD_PPL")) ppl = atoi(e);
 #define PINGS_BLEND_BWD(M, L)                                                                            \
   hipLaunchKernelGGL((blend_bwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, bp, bs.ranges,    \
-                     bs.point_list, gs.rec, gs.rect, im.final_T, im.n_contrib, out_depth, dL_dcolor,     \
+                     bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor,     \
                      dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx, bw.rows)
     if (s->mode == PINGS_RASTER_SURFEL) {
       if (ppl == 1) PINGS_BLEND_BWD(MODE_SURFEL, 1);

@@ -30,6 +30,10 @@ constexpr float T_EPS = 1e-4f;
 constexpr float DEPTH_ALPHA_EPS = 1e-10f;
 constexpr float DEN_EPS = 1e-6f;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
+// occlusion culling of instances (see occl_budget_kernel)
+constexpr float OCC_THR = 9.5f;     // > -ln(T_EPS) = 9.21: transmittance bound that guarantees every pixel has stopped
+constexpr float OCC_FIX = 4096.f;   // fixed-point scale of the budget (integer atomics: order independent)
+constexpr uint16_t OCC_ALL = 0xFFFFu;
 
 constexpr int MODE_SURFEL = 0;
 constexpr int MODE_3DGS = 1;
@@ -62,14 +66,20 @@ struct GeomState {
   float4* rec;
   uint4* rect;
   uint32_t *depth_key, *depth_key_sorted, *gidx, *gidx_sorted;
-  uint32_t *tiles_sorted, *offsets_sorted;
+  uint32_t *tiles_sorted, *offsets_sorted;  // per depth rank: KEPT tiles of the Gaussian and their inclusive scan
+  uint32_t* occ_bucket;                     // [occ_nb][num_tiles] fixed-point opacity budget per (rank bucket, tile)
+  uint16_t* occ_bsat;                       // [num_tiles] last rank bucket a tile still needs (0xFFFF = all)
+  uint32_t* nvalid;                         // [1] Gaussians that survived culling (= ranks with a real depth key)
+  int occ_nb;
   char* temp;
   size_t temp_bytes;
   size_t total;
 };
 
 struct BinState {
-  uint32_t *tile_key, *tile_key_sorted, *gval, *point_list;
+  // pre-sort, slot order (= depth rank, then tile order inside the Gaussian's rectangle): tile_key[slot],
+  // gval[slot] = Gaussian id, slot_val[slot] = slot;  sorted by tile: point_list[i] = slot
+  uint32_t *tile_key, *tile_key_sorted, *gval, *slot_val, *point_list;
   uint2* ranges;
   float* inst_w;       // [I+1] per-instance sum of blend weights (0 = instance never blended)
   uint32_t* inst_cnt;  // [I]   per-instance pixel count with transmittance > 0.5 (3DGS)
@@ -84,7 +94,8 @@ struct ImageState {
   size_t total;
 };
 
-GeomState carve_geom(void* blob, int P);
+GeomState carve_geom(void* blob, int P, int num_tiles);
+int occlusion_buckets(int num_tiles);
 BinState carve_binning(void* blob, int64_t I, int num_tiles);
 ImageState carve_image(void* blob, int W, int H);
 
@@ -126,7 +137,8 @@ __device__ inline float wave_sum_to_all(float v) {
 __device__ inline float edge_min_q(float a, float b, float c, float d_fixed, float lo, float hi) {
   // q along the edge {fixed offset d_fixed on one axis, free offset t in [lo, hi] on the other}:
   //   q(t) = a d^2 + 2 b d t + c t^2, minimised at t* = -b d / c, clamped to the edge
-  const float t = fminf(fmaxf(-(b * d_fixed) / c, lo), hi);
+  // (1-ulp reciprocal: an error dt in t raises q by c dt^2 ~ 1e-14 c t^2, far below the margin)
+  const float t = fminf(fmaxf(-(b * d_fixed) * __builtin_amdgcn_rcpf(c), lo), hi);
   const float q0 = a * d_fixed * d_fixed, q1 = 2.f * b * d_fixed * t, q2 = c * t * t;
   return (q0 + q1 + q2) - 2e-5f * (q0 + fabsf(q1) + q2);
 }

@@ -53,10 +53,18 @@ static size_t sort_temp_bytes(int64_t n) {
   return align_up(a > b ? a : b) + 256;
 }
 
-GeomState carve_geom(void* blob, int P) {
+// rank buckets per tile of the occlusion budget: ~2M counters in total, 32..256 per tile
+int occlusion_buckets(int num_tiles) {
+  int nb = 256;
+  while (nb > 32 && (size_t)nb * (size_t)num_tiles > ((size_t)1 << 21)) nb >>= 1;
+  return nb;
+}
+
+GeomState carve_geom(void* blob, int P, int num_tiles) {
   Carver c(blob);
   GeomState g;
   const size_t n = (size_t)(P > 0 ? P : 1);
+  const size_t nt = (size_t)(num_tiles > 0 ? num_tiles : 1);
   g.rec = c.take<float4>(4 * n);
   g.rect = c.take<uint4>(n);
   g.depth_key = c.take<uint32_t>(n);
@@ -65,6 +73,10 @@ GeomState carve_geom(void* blob, int P) {
   g.gidx_sorted = c.take<uint32_t>(n);
   g.tiles_sorted = c.take<uint32_t>(n);
   g.offsets_sorted = c.take<uint32_t>(n);
+  g.occ_nb = occlusion_buckets((int)nt);
+  g.occ_bucket = c.take<uint32_t>(nt * (size_t)g.occ_nb);
+  g.occ_bsat = c.take<uint16_t>(nt);
+  g.nvalid = c.take<uint32_t>(1);
   g.temp_bytes = sort_temp_bytes((int64_t)n);
   g.temp = c.take<char>(g.temp_bytes);
   g.total = c.off;
@@ -82,6 +94,7 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.tile_key = c.take<uint32_t>(n);
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
+  b.slot_val = c.take<uint32_t>(n);
   b.temp_bytes = sort_temp_bytes((int64_t)n);
   b.temp = c.take<char>(b.temp_bytes);
   b.total = c.off;
@@ -237,14 +250,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   rec[4 * g + 3] = make_float4(nx, ny, nz, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void gather_tiles_kernel(int P, const uint32_t* __restrict__ gidx_sorted,
-                                                            const uint4* __restrict__ rect,
-                                                            uint32_t* __restrict__ tiles_sorted) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  tiles_sorted[r] = rect[gidx_sorted[r]].w;
-}
-
 // Depth ranks are dealt to waves round-robin (lane l of wave w owns rank l*num_waves + w): the
 // nearest Gaussians, which cover the most tiles, sit at neighbouring ranks and would otherwise
 // all land in the first waves.
@@ -255,54 +260,227 @@ __device__ inline int strided_rank(int P) {
   return r < P ? r : -1;
 }
 
-// Emits the (tile id, Gaussian id) instances in depth order.  One lane per Gaussian rank; rects
-// of more than SMALL_RECT tiles are written by the whole wave (coalesced), the rest serially.
 constexpr int SMALL_RECT = 8;
-template <typename KeyT>
-__global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx,
-                                                         const uint32_t* __restrict__ gidx_sorted,
-                                                         const uint32_t* __restrict__ offsets_sorted,
-                                                         uint4* __restrict__ rect,
-                                                         KeyT* __restrict__ tile_key,
-                                                         uint32_t* __restrict__ gval) {
-  const int r = strided_rank(P);
+
+// Walks the tile rectangles of the depth-ranked Gaussians: one lane per rank; rectangles of more than SMALL_RECT
+// tiles are walked by the whole wave, 64 tiles per step (`coop(src_lane, k, active)` runs in every lane with its
+// own tile number k of the source lane's rectangle), the others serially by their lane (`serial(tile)`).
+struct RectLane {
+  uint32_t g, n;
+  int xmin, ymin, wdt;
+};
+template <typename Serial, typename CoopBegin, typename Coop>
+__device__ inline void walk_rects(const RectLane& me, int gx, Serial serial, CoopBegin coop_begin, Coop coop) {
   const int lane = threadIdx.x & 63;
-  uint32_t g = 0, off = 0;
-  uint4 rc = make_uint4(0u, 0u, 0u, 0u);
-  if (r >= 0) {
-    g = gidx_sorted[r];
-    rc = rect[g];
-    if (rc.w != 0u) {
-      off = offsets_sorted[r] - rc.w;
-      rc.x = off;
-      rect[g] = rc;
+  if (me.n != 0u && me.n <= (uint32_t)SMALL_RECT) {
+    int x = 0, y = 0;
+    for (uint32_t k = 0; k < me.n; ++k) {
+      serial((me.ymin + y) * gx + (me.xmin + x));
+      if (++x == me.wdt) { x = 0; ++y; }
     }
   }
-  const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF, ymax = rc.z >> 16;
-  if (rc.w != 0u && rc.w <= (uint32_t)SMALL_RECT) {
-    uint32_t o = off;
-    for (int y = ymin; y < ymax; ++y)
-      for (int x = xmin; x < xmax; ++x) {
-        tile_key[o] = (KeyT)(y * gx + x);
-        gval[o] = g;
-        ++o;
-      }
-  }
-  unsigned long long m = __ballot(rc.w > (uint32_t)SMALL_RECT);
+  unsigned long long m = __ballot(me.n > (uint32_t)SMALL_RECT);
   while (m) {
     const int src = __ffsll((long long)m) - 1;
     m &= m - 1;
-    const uint32_t n = (uint32_t)__shfl((int)rc.w, src, 64);
-    const uint32_t o = (uint32_t)__shfl((int)off, src, 64);
-    const uint32_t gg = (uint32_t)__shfl((int)g, src, 64);
-    const int x0 = __shfl(xmin, src, 64), y0 = __shfl(ymin, src, 64);
-    const int wdt = __shfl(xmax, src, 64) - x0;
-    for (uint32_t k = lane; k < n; k += 64) {
+    const uint32_t n = (uint32_t)__shfl((int)me.n, src, 64);
+    const int x0 = __shfl(me.xmin, src, 64), y0 = __shfl(me.ymin, src, 64), wdt = __shfl(me.wdt, src, 64);
+    coop_begin(src);
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+      const uint32_t k = k0 + (uint32_t)lane;
+      const bool act = k < n;
       const int yy = (int)(k / (uint32_t)wdt), xx = (int)(k - (uint32_t)yy * (uint32_t)wdt);
-      tile_key[o + k] = (KeyT)((y0 + yy) * gx + (x0 + xx));
-      gval[o + k] = gg;
+      coop(src, act ? (y0 + yy) * gx + (x0 + xx) : 0, act);
     }
   }
+}
+
+__device__ inline RectLane rect_lane(int r, const uint32_t* __restrict__ gidx_sorted, const uint4* __restrict__ rect) {
+  RectLane me{0u, 0u, 0, 0, 1};
+  if (r >= 0) {
+    me.g = gidx_sorted[r];
+    const uint4 rc = rect[me.g];
+    me.n = rc.w;
+    me.xmin = (int)(rc.y & 0xFFFF);
+    me.ymin = (int)(rc.y >> 16);
+    me.wdt = max((int)(rc.z & 0xFFFF) - me.xmin, 1);
+  }
+  return me;
+}
+
+// ---------------------------------------------------------------- occlusion culling of instances
+// A tile whose every pixel has stopped (transmittance test, T_EPS) ignores the rest of its list.  Before any
+// instance is created, a CONSERVATIVE per-tile bound finds a depth rank beyond which that is certain:
+//   * for a (Gaussian, tile) pair, a_min = lower bound of the alpha the blend kernel gives ANY pixel of the tile
+//     (largest q at the tile corners, fp32 error margins included; 0 if some pixel might be rejected by the
+//     alpha >= 1/255 or power <= 0 tests, in particular for the tile that holds the centre);
+//   * -ln(1 - a_min) is added (fixed point, integer atomics: order independent, hence reproducible) to the budget
+//     of (tile, rank bucket); ranks are the depth order, OCC buckets per tile;
+//   * the first bucket at which the running budget reaches OCC_THR > -ln(T_EPS) is the last one the tile needs:
+//     whatever alphas the other Gaussians add, every pixel has met T (1 - alpha) < T_EPS by then.
+// Instances of later buckets are never created: the sort, the per-instance arrays and the staging of the blend
+// kernels shrink to the lists that can matter (Metric-1: 16.9 M -> 1.8 M), and every output stays bit-identical,
+// because a culled instance would never have been blended.  The kept list of a tile is a prefix of its full list.
+__device__ inline float tile_min_alpha(float mx, float my, float o, float cx, float cy, float cz, float X0, float Y0) {
+  const float x1 = X0 + 15.f, y1 = Y0 + 15.f;
+  if (mx >= X0 && mx <= x1 && my >= Y0 && my <= y1) return 0.f;
+  float qmax = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float dx = ((c & 1) ? x1 : X0) - mx, dy = ((c & 2) ? y1 : Y0) - my;
+    const float q0 = cx * dx * dx, q1 = 2.f * cy * dx * dy, q2 = cz * dy * dy;
+    qmax = fmaxf(qmax, (q0 + q1 + q2) + 2e-5f * (q0 + fabsf(q1) + q2));
+  }
+  const float a = fminf(ALPHA_MAX, o * __expf(-0.5f * (qmax + 1e-3f)) * (1.f - 1e-5f));
+  if (!(a >= ALPHA_MIN * 1.001f)) return 0.f;
+  // the smallest q over the tile must be safely positive, or the kernel's `power <= 0` test might drop a pixel
+  const float lx = X0 - mx, hx = x1 - mx, ly = Y0 - my, hy = y1 - my;
+  float m = edge_min_q(cx, cy, cz, lx, ly, hy);
+  m = fminf(m, edge_min_q(cx, cy, cz, hx, ly, hy));
+  m = fminf(m, edge_min_q(cz, cy, cx, ly, lx, hx));
+  m = fminf(m, edge_min_q(cz, cy, cx, hy, lx, hx));
+  if (!(m > 1e-6f)) return 0.f;
+  return a;
+}
+
+// ranks [0, nvalid) hold the Gaussians with a real depth key (culled ones sort last): first culled rank
+__global__ void count_valid_kernel(int P, const uint32_t* __restrict__ depth_key_sorted, uint32_t* __restrict__ nvalid) {
+  int lo = 0, hi = P;  // lower bound of CULLED_KEY
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (depth_key_sorted[mid] < CULLED_KEY) lo = mid + 1; else hi = mid;
+  }
+  *nvalid = (uint32_t)lo;
+}
+
+__device__ inline uint32_t rank_bucket(int r, int nb, uint32_t nvalid) {
+  if (r < 0 || nvalid == 0u) return 0u;
+  const uint32_t b = (uint32_t)(((unsigned long long)r * (unsigned long long)nb) / (unsigned long long)nvalid);
+  return min(b, (uint32_t)nb - 1u);
+}
+
+__global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
+                                                          const uint32_t* __restrict__ gidx_sorted,
+                                                          const uint4* __restrict__ rect,
+                                                          const float4* __restrict__ rec,
+                                                          const uint32_t* __restrict__ nvalid, int num_tiles,
+                                                          uint32_t* __restrict__ bucket) {
+  const int r = strided_rank(P);
+  const RectLane me = rect_lane(r, gidx_sorted, rect);
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+  if (me.n != 0u) {
+    ra = rec[4 * (size_t)me.g + 0];
+    rb = rec[4 * (size_t)me.g + 1];
+  }
+  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  // bucket-major layout: the 64 tiles a wave handles in one step are neighbours in a tile row, so its atomics
+  // hit contiguous words (scattered 4-byte atomics run an order of magnitude slower)
+  auto add = [&](int tile, float mx, float my, float o, float cx, float cy, float cz, uint32_t b) {
+    const int tx = tile % gx, ty = tile / gx;
+    const float a = tile_min_alpha(mx, my, o, cx, cy, cz, (float)(tx * TILE), (float)(ty * TILE));
+    if (a > 0.f) atomicAdd(&bucket[(size_t)b * num_tiles + tile], (uint32_t)(-__logf(1.f - a) * OCC_FIX));
+  };
+  float smx = 0, smy = 0, so = 0, scx = 0, scy = 0, scz = 0;
+  uint32_t sb = 0;
+  walk_rects(
+      me, gx, [&](int tile) { add(tile, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, bk); },
+      [&](int src) {
+        smx = __shfl(ra.x, src, 64); smy = __shfl(ra.y, src, 64); so = __shfl(ra.z, src, 64);
+        scx = __shfl(rb.x, src, 64); scy = __shfl(rb.y, src, 64); scz = __shfl(rb.z, src, 64);
+        sb = (uint32_t)__shfl((int)bk, src, 64);
+      },
+      [&](int, int tile, bool act) { if (act) add(tile, smx, smy, so, scx, scy, scz, sb); });
+}
+
+// one thread per tile (coalesced across tiles for every bucket): running budget -> last bucket the tile needs
+__global__ __launch_bounds__(64) void occl_scan_kernel(int num_tiles, int nb, const uint32_t* __restrict__ bucket,
+                                                       uint16_t* __restrict__ bsat) {
+  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= num_tiles) return;
+  const uint32_t thr = (uint32_t)(OCC_THR * OCC_FIX);
+  uint32_t sum = 0, res = OCC_ALL;
+  for (int b0 = 0; b0 < nb && res == OCC_ALL; b0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = b0 + u < nb ? bucket[(size_t)(b0 + u) * num_tiles + tile] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sum += min(v[u], thr);
+      if (res == OCC_ALL && sum >= thr) res = (uint32_t)(b0 + u);
+    }
+  }
+  bsat[tile] = (uint16_t)res;
+}
+
+// kept tiles per depth rank (the Gaussian's rank bucket must not exceed the tile's last needed bucket)
+__global__ __launch_bounds__(256) void count_kept_kernel(int P, int gx, int nb,
+                                                         const uint32_t* __restrict__ gidx_sorted,
+                                                         const uint4* __restrict__ rect,
+                                                         const uint16_t* __restrict__ bsat,
+                                                         const uint32_t* __restrict__ nvalid,
+                                                         uint32_t* __restrict__ tiles_sorted) {
+  const int r = strided_rank(P);
+  const int lane = threadIdx.x & 63;
+  const RectLane me = rect_lane(r, gidx_sorted, rect);
+  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  uint32_t kept = 0, sb = 0, acc = 0;
+  int cur = -1;
+  walk_rects(
+      me, gx, [&](int tile) { kept += (bk <= (uint32_t)bsat[tile]) ? 1u : 0u; },
+      [&](int src) {
+        if (cur >= 0 && lane == cur) kept = acc;
+        cur = src;
+        acc = 0;
+        sb = (uint32_t)__shfl((int)bk, src, 64);
+      },
+      [&](int, int tile, bool act) { acc += (uint32_t)__popcll(__ballot(act && sb <= (uint32_t)bsat[tile])); });
+  if (cur >= 0 && lane == cur) kept = acc;
+  if (r >= 0) tiles_sorted[r] = kept;
+}
+
+// Emits the kept (tile id, slot) instances in depth order; gval[slot] = Gaussian id, slot_val[slot] = slot.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int nb,
+                                                         const uint32_t* __restrict__ gidx_sorted,
+                                                         const uint32_t* __restrict__ offsets_sorted,
+                                                         const uint32_t* __restrict__ tiles_sorted,
+                                                         const uint4* __restrict__ rect,
+                                                         const uint16_t* __restrict__ bsat,
+                                                         const uint32_t* __restrict__ nvalid,
+                                                         KeyT* __restrict__ tile_key,
+                                                         uint32_t* __restrict__ gval,
+                                                         uint32_t* __restrict__ slot_val) {
+  const int r = strided_rank(P);
+  const RectLane me = rect_lane(r, gidx_sorted, rect);
+  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  uint32_t o = r >= 0 ? offsets_sorted[r] - tiles_sorted[r] : 0u;  // first slot of this Gaussian
+  uint32_t sb = 0, so = 0, sg = 0;
+  walk_rects(
+      me, gx,
+      [&](int tile) {
+        if (bk <= (uint32_t)bsat[tile]) {
+          tile_key[o] = (KeyT)tile;
+          gval[o] = me.g;
+          slot_val[o] = o;
+          ++o;
+        }
+      },
+      [&](int src) {
+        sb = (uint32_t)__shfl((int)bk, src, 64);
+        so = (uint32_t)__shfl((int)o, src, 64);
+        sg = (uint32_t)__shfl((int)me.g, src, 64);
+      },
+      [&](int, int tile, bool act) {
+        const bool keep = act && sb <= (uint32_t)bsat[tile];
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+          const uint32_t pos = so + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          tile_key[pos] = (KeyT)tile;
+          gval[pos] = sg;
+          slot_val[pos] = pos;
+        }
+        so += (uint32_t)__popcll(bal);
+      });
 }
 
 template <typename KeyT>
@@ -333,7 +511,7 @@ __device__ unsigned long long g_blend_stats[8];
 template <int MODE, int PPL>
 __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ rec, const uint4* __restrict__ rect, float* __restrict__ out_color,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_w,
     uint32_t* __restrict__ inst_cnt) {
@@ -402,16 +580,15 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     for (int rr = 0; rr < PPL; ++rr) {
       const int e = tid + rr * NT;
       if (e < n) {
-        const uint32_t g = point_list[range.x + base + e];
+        const uint32_t slot = point_list[range.x + base + e];
+        const uint32_t g = gval[slot];
         const float4 ra = rec[4 * (size_t)g + 0];
         const float4 rb = rec[4 * (size_t)g + 1];
         sA[e] = ra;
         sB[e] = rb;
         sC[e] = rec[4 * (size_t)g + 2];
         if (MODE == MODE_SURFEL) sD[e] = rec[4 * (size_t)g + 3];
-        const uint4 rc = rect[g];
-        const int xmin = rc.y & 0xFFFF, ymin = rc.y >> 16, xmax = rc.z & 0xFFFF;
-        sSlot[e] = rc.x + (uint32_t)((ty - ymin) * (xmax - xmin) + (tx - xmin));
+        sSlot[e] = slot;
         sMask[e] = (uint8_t)quadrant_mask(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, tileX0, tileY0);
 #pragma unroll
         for (int wv = 0; wv < NWV; ++wv) {
@@ -662,7 +839,10 @@ PINGS_API int pings_raster_mark_visible(const float* positions, int N,
   return PINGS_OK;
 }
 
-PINGS_API size_t pings_raster_geom_bytes(int P) { return carve_geom(nullptr, P).total; }
+PINGS_API size_t pings_raster_geom_bytes(int P, int image_height, int image_width) {
+  const int nt = pings::ceil_div(image_width, TILE) * pings::ceil_div(image_height, TILE);
+  return carve_geom(nullptr, P, nt).total;
+}
 
 PINGS_API size_t pings_raster_binning_bytes(int64_t num_instances, int image_height,
                                             int image_width) {
@@ -687,7 +867,8 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
   PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob && radii,
                   "null pointer");
   hipStream_t st = pings::as_stream(stream);
-  GeomState gs = carve_geom(geom_blob, P);
+  const int num_tiles = kp.gx * kp.gy;
+  GeomState gs = carve_geom(geom_blob, P, num_tiles);
   const dim3 grid(pings::ceil_div(P, 256)), block(256);
   {
     pings::prof::Scope ps("preprocess", st);
@@ -705,10 +886,27 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
     PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
                                                        gs.gidx, gs.gidx_sorted, P, 0, 32, st));
   }
+  // PINGS_RASTER_OCCLUSION=0 keeps every (Gaussian, tile) instance (A/B runs, list-parity tests)
+  bool occlusion = true;
+  if (const char* e = getenv("PINGS_RASTER_OCCLUSION")) occlusion = atoi(e) != 0;
+  if (occlusion) {
+    pings::prof::Scope ps("occlusion", st);
+    PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bucket, 0, sizeof(uint32_t) * (size_t)num_tiles * gs.occ_nb, st));
+    hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1), 0, st, P, gs.depth_key_sorted, gs.nvalid);
+    hipLaunchKernelGGL(occl_budget_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
+                       gs.rec, gs.nvalid, num_tiles, gs.occ_bucket);
+    PINGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(occl_scan_kernel, dim3(pings::ceil_div(num_tiles, 64)), dim3(64), 0, st, num_tiles,
+                       gs.occ_nb, gs.occ_bucket, gs.occ_bsat);
+    PINGS_LAUNCH_CHECK();
+  } else {
+    PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bsat, 0xFF, sizeof(uint16_t) * (size_t)num_tiles, st));
+    PINGS_HIP_CHECK(hipMemsetAsync(gs.nvalid, 0, sizeof(uint32_t), st));
+  }
   {
     pings::prof::Scope ps("tile_count_scan", st);
-    hipLaunchKernelGGL(gather_tiles_kernel, grid, block, 0, st, P, gs.gidx_sorted, gs.rect,
-                       gs.tiles_sorted);
+    hipLaunchKernelGGL(count_kept_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
+                       gs.occ_bsat, gs.nvalid, gs.tiles_sorted);
     PINGS_LAUNCH_CHECK();
     tb = gs.temp_bytes;
     PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
@@ -735,7 +933,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   PINGS_ARG_CHECK(P == 0 || (geom_blob && per_gaussian), "null pointer");
   hipStream_t st = pings::as_stream(stream);
   const int num_tiles = kp.gx * kp.gy;
-  GeomState gs = carve_geom(geom_blob, P);
+  GeomState gs = carve_geom(geom_blob, P, num_tiles);
   BinState bs = carve_binning(binning_blob, I, num_tiles);
   ImageState im = carve_image(image_blob, kp.W, kp.H);
 
@@ -749,22 +947,24 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
       pings::prof::Scope ps("duplicate", st);
       if (k16)
         hipLaunchKernelGGL(duplicate_kernel<uint16_t>, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P,
-                           kp.gx, gs.gidx_sorted, gs.offsets_sorted, gs.rect, key16, bs.gval);
+                           kp.gx, gs.occ_nb, gs.gidx_sorted, gs.offsets_sorted, gs.tiles_sorted, gs.rect,
+                           gs.occ_bsat, gs.nvalid, key16, bs.gval, bs.slot_val);
       else
         hipLaunchKernelGGL(duplicate_kernel<uint32_t>, dim3(pings::ceil_div(P, 256)), dim3(256), 0, st, P,
-                           kp.gx, gs.gidx_sorted, gs.offsets_sorted, gs.rect, bs.tile_key, bs.gval);
+                           kp.gx, gs.occ_nb, gs.gidx_sorted, gs.offsets_sorted, gs.tiles_sorted, gs.rect,
+                           gs.occ_bsat, gs.nvalid, bs.tile_key, bs.gval, bs.slot_val);
       PINGS_LAUNCH_CHECK();
     }
     {
       pings::prof::Scope ps("tile_sort", st);
       size_t tb = bs.temp_bytes;
       if (k16)
-        PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, key16, key16s, bs.gval,
+        PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, key16, key16s, bs.slot_val,
                                                            bs.point_list, (int)I, 0, tile_bits(num_tiles),
                                                            st));
       else
         PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(bs.temp, tb, bs.tile_key, bs.tile_key_sorted,
-                                                           bs.gval, bs.point_list, (int)I, 0,
+                                                           bs.slot_val, bs.point_list, (int)I, 0,
                                                            tile_bits(num_tiles), st));
     }
     {
@@ -790,7 +990,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
 #define PINGS_BLEND_FWD(M, L)                                                                          \
   hipLaunchKernelGGL((blend_fwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, kp, bs.ranges,  \
-                     bs.point_list, gs.rec, gs.rect, out_color, out_normal, out_depth, out_alpha,      \
+                     bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,      \
                      im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt)
   if (s->mode == PINGS_RASTER_SURFEL) {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
@@ -821,6 +1021,12 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   return PINGS_OK;
 }
 
+__global__ void slots_to_ids_kernel(int64_t I, const uint32_t* __restrict__ list, const uint32_t* __restrict__ gval,
+                                    uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < I) out[i] = gval[list[i]];
+}
+
 #ifdef PINGS_BLEND_STATS
 PINGS_API int pings_debug_blend_stats(unsigned long long* out8, int reset) {
   PINGS_HIP_CHECK(hipDeviceSynchronize());
@@ -840,9 +1046,11 @@ PINGS_API int pings_raster_debug_lists(const void* binning_blob, int64_t I, int 
   const int nt = pings::ceil_div(image_width, TILE) * pings::ceil_div(image_height, TILE);
   BinState bs = carve_binning(const_cast<void*>(binning_blob), I, nt);
   hipStream_t st = pings::as_stream(stream);
-  if (I > 0 && point_list)
-    PINGS_HIP_CHECK(hipMemcpyAsync(point_list, bs.point_list, sizeof(uint32_t) * (size_t)I,
-                                   hipMemcpyDeviceToDevice, st));
+  if (I > 0 && point_list) {  // sorted list holds instance slots; the tap returns Gaussian ids
+    hipLaunchKernelGGL(slots_to_ids_kernel, dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), dim3(256), 0, st, I,
+                       bs.point_list, bs.gval, point_list);
+    PINGS_LAUNCH_CHECK();
+  }
   PINGS_HIP_CHECK(hipMemcpyAsync(ranges_xy, bs.ranges, sizeof(uint2) * (size_t)nt,
                                  hipMemcpyDeviceToDevice, st));
   return PINGS_OK;

@@ -130,7 +130,7 @@ def _declare(L):
     L.pings_raster_mark_visible.restype = C.c_int
     L.pings_raster_mark_visible.argtypes = [vp, i32, C.POINTER(_CSettings), vp, vp]
     L.pings_raster_geom_bytes.restype = C.c_size_t
-    L.pings_raster_geom_bytes.argtypes = [i32]
+    L.pings_raster_geom_bytes.argtypes = [i32, i32, i32]
     L.pings_raster_binning_bytes.restype = C.c_size_t
     L.pings_raster_binning_bytes.argtypes = [i64, i32, i32]
     L.pings_raster_image_bytes.restype = C.c_size_t
@@ -185,7 +185,7 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     u8 = dict(dtype=torch.uint8, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
     stream = _lib.stream_ptr(dev)
-    geom = torch.empty(L.pings_raster_geom_bytes(P), **u8)
+    geom = torch.empty(L.pings_raster_geom_bytes(P, H, W), **u8)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
     n_inst = C.c_int64(0)
     st = L.pings_raster_preprocess(prep.ref(), P, _lib.ptr(means3D), _lib.ptr(colors),

@@ -130,19 +130,44 @@ def _hip_forward(sc, mode, front_only, scale_modifier=1.0):
     return hr, prep, fs, radii, per_g
 
 
+def _check_list_prefixes(pl, rg, nc, o, W, H):
+    """Occlusion culling (csrc/raster_fwd.hip: occl_budget_kernel) drops the instances of a tile behind the depth
+    rank at which the tile is provably saturated: every kept list must be a PREFIX of the oracle's (tile, depth,
+    index)-sorted list and must hold every record a pixel of the tile blended (n_contrib)."""
+    pl, rg = pl.cpu().numpy(), rg.cpu().numpy()
+    opl, org = o["point_list"], o["ranges"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ncp = np.zeros((gy * 16, gx * 16), dtype=np.int64)
+    ncp[:H, :W] = nc.cpu().numpy()
+    need = ncp.reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(gy * gx, 256).max(1)
+    assert rg.shape == org.shape
+    total = 0
+    for t in range(rg.shape[0]):
+        n, on = rg[t, 1] - rg[t, 0], org[t, 1] - org[t, 0]
+        assert 0 <= n <= on and n >= need[t], (t, n, on, need[t])
+        assert np.array_equal(pl[rg[t, 0]:rg[t, 1]], opl[org[t, 0]:org[t, 0] + n]), t
+        total += n
+    assert total == len(pl)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("occlusion", ["1", "0"])
 @pytest.mark.parametrize("mode,front_only,seed", CASES)
 @pytest.mark.parametrize("size", [(700, 112, 80), (1500, 200, 120), (40, 33, 17)])
-def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size):
+def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size, occlusion, monkeypatch):
+    monkeypatch.setenv("PINGS_RASTER_OCCLUSION", occlusion)
     P, W, H = size
     sc = make_scene(P, W, H, seed=seed, surfel=(mode == "surfel"))
     o, *_ = _oracle(sc, torch.float32, mode, front_only)
     hr, prep, fs, radii, per_g = _hip_forward(sc, mode, front_only)
     pl, rg, fT, nc = hr.debug_lists(fs)
-    assert fs.I == len(o["point_list"])
     assert (radii.cpu() == o["radii"]).all()                       # bit-exact
-    assert np.array_equal(pl.cpu().numpy(), o["point_list"])       # bit-exact sort order
-    assert np.array_equal(rg.cpu().numpy(), o["ranges"])           # bit-exact tile ranges
+    if occlusion == "0":
+        assert fs.I == len(o["point_list"])
+        assert np.array_equal(pl.cpu().numpy(), o["point_list"])   # bit-exact sort order
+        assert np.array_equal(rg.cpu().numpy(), o["ranges"])       # bit-exact tile ranges
+    else:
+        _check_list_prefixes(pl, rg, nc, o, W, H)                  # bit-exact prefix of every tile's list
     assert (nc.cpu() == o["n_contrib"]).all()
     o64, *_ = _oracle(sc, torch.float64, mode, front_only)
     assert rel_err(fs.color, o64["color"]) <= 1e-4
@@ -292,6 +317,10 @@ def test_full_size_properties_1m_gaussians_1080p():
     # (1) ranges partition the instance list; per-tile depth order, ties by index
     lens = rg[:, 1] - rg[:, 0]
     assert int(lens.sum()) == fs.I and int(rg[:, 1].max()) == fs.I
+    ncp = torch.zeros(((H + 15) // 16) * 16, ((W + 15) // 16) * 16, dtype=torch.int64, device=dev)
+    ncp[:H, :W] = nc
+    need = ncp.view((H + 15) // 16, 16, (W + 15) // 16, 16).permute(0, 2, 1, 3).reshape(-1, 256).max(1).values
+    assert bool((lens >= need).all())       # occlusion culling kept every record a pixel blended
     depth = (means @ cam["viewmatrix"][:3, 2] + cam["viewmatrix"][3, 2])
     d = depth[pl]
     tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), lens)
@@ -332,3 +361,58 @@ def test_full_size_properties_1m_gaussians_1080p():
         assert (c.double() - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-20)
     for a, b in zip(ga, grads(G1)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["surfel", "3dgs"])
+def test_occlusion_culling_changes_no_output_bit(mode, monkeypatch):
+    """A wall of large, nearly opaque Gaussians in front of a dense cloud: most instances behind the wall are
+    never created, yet images, per-Gaussian outputs and all gradients are bitwise those of the un-culled run,
+    and both match the oracle."""
+    from pings_amd import rasterizer as hr
+
+    W, H = 160, 96
+    sc = make_scene(4000, W, H, seed=77, surfel=(mode == "surfel"))
+    g = torch.Generator().manual_seed(3)
+    nw = 300                                                    # the wall: first nw Gaussians, 1.2 m in front
+    V = sc["cam"]["viewmatrix"].to(sc["means"].dtype)           # X_c = X_w @ V[:3,:3] + V[3,:3]
+    pc = sc["means"] @ V[:3, :3] + V[3, :3]
+    pc[:nw, 0] = (torch.rand(nw, generator=g, dtype=pc.dtype) - 0.5) * 3.0
+    pc[:nw, 1] = (torch.rand(nw, generator=g, dtype=pc.dtype) - 0.5) * 2.0
+    pc[:nw, 2] = 1.2 + 0.05 * torch.rand(nw, generator=g, dtype=pc.dtype)
+    pc[nw:, 2] = pc[nw:, 2].abs() + 2.0
+    sc["means"] = (pc - V[3, :3]) @ torch.linalg.inv(V[:3, :3])
+    sc["scales"][:nw, :2] = 0.6
+    sc["op"][:nw] = 0.95
+
+    def run(flag):
+        monkeypatch.setenv("PINGS_RASTER_OCCLUSION", flag)
+        hs = hip_settings(sc, mode, False, 1.0)
+        rast = (hr.SurfelGaussianRasterizer if mode == "surfel" else hr.GS3DGaussianRasterizer)(hs)
+        leaves = [sc[k].to(torch.float32).cuda().contiguous().requires_grad_(True)
+                  for k in ("means", "col", "op", "scales", "rot")]
+        th = torch.zeros(3, device="cuda", requires_grad=True)
+        rh = torch.zeros(3, device="cuda", requires_grad=True)
+        out = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), colors_precomp=leaves[1],
+                   opacities=leaves[2], scales=leaves[3], rotations=leaves[4], theta=th, rho=rh)
+        imgs = [t for t in out if t.is_floating_point() and t.dim() == 3]
+        gg = torch.Generator(device="cuda").manual_seed(9)
+        torch.autograd.backward(imgs, [torch.randn(t.shape, generator=gg, device="cuda") for t in imgs])
+        prep = rast._prepared()
+        fs, _, _ = hr._forward(prep, *[t.detach() for t in leaves])
+        return out, [t.grad for t in leaves] + [th.grad, rh.grad], fs.I
+
+    out1, g1, I1 = run("1")
+    out0, g0, I0 = run("0")
+    assert I1 < 0.6 * I0, (I1, I0)                            # the wall really hides most of the cloud
+    for a, b in zip(out1, out0):
+        if a.dim() == 1 and a.is_floating_point():
+            # contributions: the same non-zero per-instance sums, added in an order that depends on how many
+            # instances the Gaussian has (serial <= 16, wave-cooperative above): equal up to fp32 association
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+        else:
+            assert torch.equal(a, b)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    o, *_ = _oracle(sc, torch.float64, mode, False)
+    assert rel_err(out1[0], o["color"]) <= 1e-4
