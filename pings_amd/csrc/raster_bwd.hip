@@ -747,7 +747,7 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   }
   if (I > 0) {
     pings::prof::Scope ps("blend_bwd", st);
-    int ppl = 2;
+    int ppl = blend_ppl_hint();
     if (const char* e = getenv("PINGS_BLEND_BWD_PPL")) ppl = atoi(e);
 #define PINGS_BLEND_BWD(M, L)                                                                            \
   hipLaunchKernelGGL((blend_bwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, bp, bs.ranges,    \

@@ -70,6 +70,7 @@ struct GeomState {
   uint32_t* occ_bucket;                     // [occ_nb][num_tiles] fixed-point opacity budget per (rank bucket, tile)
   uint16_t* occ_bsat;                       // [num_tiles] last rank bucket a tile still needs (0xFFFF = all)
   uint32_t* nvalid;                         // [1] Gaussians that survived culling (= ranks with a real depth key)
+  unsigned long long* stats;                // [2] pairs before occlusion culling, visible Gaussians
   int occ_nb;
   char* temp;
   size_t temp_bytes;
@@ -95,6 +96,10 @@ struct ImageState {
 };
 
 GeomState carve_geom(void* blob, int P, int num_tiles);
+// Pixels per lane the blend kernels of this thread's current view should use (1 or 2): chosen by
+// pings_raster_preprocess from the mean footprint (tiles per visible Gaussian), used by the render and
+// backward calls that follow on the same thread.  A stale value only costs speed.
+int& blend_ppl_hint();
 int occlusion_buckets(int num_tiles);
 BinState carve_binning(void* blob, int64_t I, int num_tiles);
 ImageState carve_image(void* blob, int W, int H);
