@@ -136,14 +136,14 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
   const uint2 range = ranges[tile];
   uint32_t last[PPL];
   float T[PPL], gC0[PPL], gC1[PPL], gC2[PPL], gN0[PPL], gN1[PPL], gN2[PPL], gD[PPL], coefT[PPL];
-  float B0[PPL], B1[PPL], B2[PPL], BN0[PPL], BN1[PPL], BN2[PPL], BD[PPL];
+  float Bs[PPL];  // blend of s = (upstream gradient) . (record features) over the records behind, normalised
   uint32_t lmax = 0;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     last[k] = 0;
     T[k] = 1.f;
     gC0[k] = gC1[k] = gC2[k] = gN0[k] = gN1[k] = gN2[k] = gD[k] = coefT[k] = 0.f;
-    B0[k] = B1[k] = B2[k] = BN0[k] = BN1[k] = BN2[k] = BD[k] = 0.f;
+    Bs[k] = 0.f;
     const int pix_y = pix_y0 + YS * k;
     if (pix_x < p.W && pix_y < p.H) {
       const size_t pix_id = (size_t)pix_y * p.W + pix_x;
@@ -272,27 +272,23 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
         const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
         const float Tn = T[k] * inv_one_m;
         const float w = valid[k] ? alpha[k] * Tn : 0.f;
-        float dLda = ((cc.x - B0[k]) * gC0[k] + (cc.y - B1[k]) * gC1[k]) + (cc.z - B2[k]) * gC2[k];
-        const float av = valid[k] ? alpha[k] : 0.f;  // B <- B + alpha (v - B) only for contributing lanes
-        B0[k] = fmaf(av, cc.x - B0[k], B0[k]);
-        B1[k] = fmaf(av, cc.y - B1[k], B1[k]);
-        B2[k] = fmaf(av, cc.z - B2[k], B2[k]);
+        // dL/dalpha needs sum_ch (feature_ch - B_ch) g_ch with B the normalised blend of the records behind.  Both
+        // the blend recurrence and the dot product are linear, so ONE scalar per pixel is tracked instead of the
+        // eight channels:  s = g . feature,  dLda = s - Bs,  Bs <- Bs + alpha (s - Bs).
+        float sdot = (cc.x * gC0[k] + cc.y * gC1[k]) + cc.z * gC2[k];
+        const float av = valid[k] ? alpha[k] : 0.f;  // only contributing lanes enter the blend
         v[G_R] = fmaf(gC0[k], w, v[G_R]);
         v[G_G] = fmaf(gC1[k], w, v[G_G]);
         v[G_B] = fmaf(gC2[k], w, v[G_B]);
         if (MODE == MODE_SURFEL) {
-          dLda += ((cn.x - BN0[k]) * gN0[k] + (cn.y - BN1[k]) * gN1[k]) + (cn.z - BN2[k]) * gN2[k];
-          BN0[k] = fmaf(av, cn.x - BN0[k], BN0[k]);
-          BN1[k] = fmaf(av, cn.y - BN1[k], BN1[k]);
-          BN2[k] = fmaf(av, cn.z - BN2[k], BN2[k]);
+          sdot += (cn.x * gN0[k] + cn.y * gN1[k]) + cn.z * gN2[k];
           // per-pixel depth of this surfel
           const float den = (cn.x * rx + cn.y * ry[k]) + cn.z;
           const bool hit = den < -DEN_EPS;
           const float inv_den = __builtin_amdgcn_rcpf(den);
           const float d0 = hit ? cc.w * inv_den : ca.w;
           const float d = fminf(fmaxf(d0, zlo), zhi);
-          dLda += (d - BD[k]) * gD[k];
-          BD[k] = fmaf(av, d - BD[k], BD[k]);
+          sdot = fmaf(d, gD[k], sdot);
           const float gd = gD[k] * w;
           const bool lo = d0 < zlo, hi = d0 > zhi;
           const bool mid = !lo && !hi;
@@ -306,10 +302,11 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
           v[G_NY] += fmaf(gden, ry[k], gN1[k] * w);
           v[G_NZ] += gN2[k] * w + gden;
         } else {
-          dLda += (ca.w - BD[k]) * gD[k];
-          BD[k] = fmaf(av, ca.w - BD[k], BD[k]);
+          sdot = fmaf(ca.w, gD[k], sdot);
           v[G_PZ] = fmaf(gD[k], w, v[G_PZ]);
         }
+        float dLda = sdot - Bs[k];
+        Bs[k] = fmaf(av, dLda, Bs[k]);
         dLda = fmaf(dLda, Tn, coefT[k] * inv_one_m);
         // alpha = min(0.99, opacity * G): no gradient through the clamp when it is active
         dLda = (valid[k] && raw[k] <= ALPHA_MAX) ? dLda : 0.f;
