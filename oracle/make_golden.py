@@ -1,7 +1,7 @@
 """Generate the golden fixtures under tests/golden/ by running the REFERENCE's
 own Python on CPU (build container only; see oracle/ref_shim.py).
 
-    python -m oracle.make_golden [group ...]      # groups: ssim sdf spawn camera
+    python -m oracle.make_golden [group ...]      # groups: ssim sdf spawn camera map
 
 Fixtures are data only (inputs + the reference's outputs), small enough to be
 committed; the reference itself never travels to the GPU box.
@@ -286,7 +286,87 @@ def make_camera(R):
         print(f"camera_{name}: ok")
 
 
-GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera}
+# ---------------------------------------------------------------- G8 map maintenance
+MAP_CASES = {
+    # KITTI-style: 0.25 m voxels, travel-distance window on, 2-D range filter (config.py:60 default)
+    "slam_v025": dict(cfg=dict(voxel_size_m=0.25, feature_dim=32, color_feature_dim=16, buffer_size=200003,
+                               range_filter_2d=True, use_mid_ts=False), diff_travel=2.0, frames=4),
+    # RGB-D style: 0.4 m voxels (1/0.4 is not exact in fp32), 3-D range filter, mid timestamps, tight window
+    "rgbd_v040": dict(cfg=dict(voxel_size_m=0.4, feature_dim=8, color_feature_dim=8, buffer_size=30011,
+                               range_filter_2d=False, use_mid_ts=True), diff_travel=0.9, frames=4),
+}
+
+
+def make_map(R):
+    """G8: NeuralPoints.update / reset_local_map / assign_local_to_global and voxel_down_sample_torch over a few
+    synthetic frames (moving sensor, re-observed surface, invalid colours, unreliable frame, hash collisions with
+    the small table)."""
+    from utils.tools import voxel_down_sample_torch  # type: ignore
+
+    for name, case in MAP_CASES.items():
+        gen = torch.Generator().manual_seed(len(name) * 7)
+        torch.manual_seed(3)
+        cfg = R.make_config(**case["cfg"])
+        cfg.local_map_radius = 4.0
+        cfg.sorrounding_map_radius = 6.0
+        cfg.color_on = True
+        npm = R.NeuralPoints(cfg)
+        nf = case["frames"]
+        npm.travel_dist = torch.tensor([0.0, 0.8, 1.7, 2.9, 3.5][:nf + 1], dtype=torch.float32)
+        npm.diff_travel_dist_local = case["diff_travel"]
+        out = dict(buffer_size=np.int64(cfg.buffer_size), resolution=np.float64(npm.resolution),
+                   travel_dist=_np(npm.travel_dist), diff_travel_dist_local=np.float64(npm.diff_travel_dist_local),
+                   local_map_radius=np.float64(cfg.local_map_radius),
+                   sorrounding_map_radius=np.float64(npm.sorrounding_map_radius),
+                   range_filter_2d=np.bool_(cfg.range_filter_2d), use_mid_ts=np.bool_(cfg.use_mid_ts),
+                   temporal_local_map_on=np.bool_(npm.temporal_local_map_on), frames=np.int64(nf),
+                   geo_dim=np.int64(cfg.feature_dim), color_dim=np.int64(cfg.color_feature_dim))
+        for ts in range(nf):
+            n = 3000
+            pts = _wavy_points(n, gen, extent=5.0) + torch.tensor([0.7 * ts, 0.1 * ts, 0.0])
+            pts = pts + 0.01 * torch.randn(n, 3, generator=gen)
+            cols = torch.rand(n, 3, generator=gen)
+            cols[torch.rand(n, generator=gen) < 0.2, 0] = -1.0          # invalid colours
+            sensor = torch.tensor([0.7 * ts, 0.1 * ts, 0.5])
+            n_old = npm.count()
+            sidx = voxel_down_sample_torch(pts, npm.resolution)
+            ratio = npm.update(pts, cols, None, None, None, cur_ts=ts, is_reliable=(ts != 1))
+            n_new = npm.count() - n_old
+            f = f"f{ts}_"
+            out.update({f + "points": _np(pts), f + "colors": _np(cols), f + "sensor": _np(sensor),
+                        f + "sample_idx": _np(sidx), f + "ratio": np.float64(ratio), f + "n_new": np.int64(n_new),
+                        f + "new_geo": _np(npm.geo_features[n_old:]), f + "new_color": _np(npm.color_features[n_old:]),
+                        f + "neural_points": _np(npm.neural_points), f + "point_colors": _np(npm.point_colors),
+                        f + "valid_color_mask": _np(npm.valid_color_mask), f + "free_gs_mask": _np(npm.free_gs_mask),
+                        f + "point_ts_create": _np(npm.point_ts_create), f + "point_ts_update": _np(npm.point_ts_update)})
+            tab = npm.buffer_pt_index
+            nz = torch.nonzero(tab >= 0).flatten()
+            out.update({f + "table_slots": _np(nz), f + "table_vals": _np(tab[nz])})
+            npm.reset_local_map(sensor, torch.eye(3), cur_ts=ts)
+            out.update({f + "local_mask": _np(npm.local_mask), f + "sorrounding_mask": _np(npm.sorrounding_mask),
+                        f + "global2local": _np(npm.global2local),
+                        f + "local_neural_points": _np(npm.local_neural_points),
+                        f + "local_point_ts_update": _np(npm.local_point_ts_update),
+                        f + "local_point_colors": _np(npm.local_point_colors),
+                        f + "local_valid_color_mask": _np(npm.local_valid_color_mask),
+                        f + "local_free_gs_mask": _np(npm.local_free_gs_mask),
+                        f + "local_geo_features": _np(npm.local_geo_features)})
+            # what a mapping step would do to the local copies, then write-back
+            with torch.no_grad():
+                npm.local_geo_features += 0.01 * (ts + 1)
+                npm.local_color_features -= 0.02 * (ts + 1)
+            npm.local_point_certainties = npm.local_point_certainties + 0.5
+            npm.local_point_ts_update = torch.full_like(npm.local_point_ts_update, ts)
+            npm.assign_local_to_global()
+            out.update({f + "geo_features_after": _np(npm.geo_features), f + "color_features_after": _np(npm.color_features),
+                        f + "point_certainties_after": _np(npm.point_certainties),
+                        f + "point_ts_update_after": _np(npm.point_ts_update)})
+            print(f"map_{name} frame {ts}: samples={sidx.numel()} new={n_new} total={npm.count()} "
+                  f"local={npm.local_count()} ratio={ratio:.3f}")
+        np.savez_compressed(OUT / f"map_{name}.npz", **out)
+
+
+GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map}
 
 
 def main(argv):
