@@ -343,4 +343,50 @@ PINGS_API int pings_spawn_backward(const pings_spawn_params* p, const float* xyz
                                    float* dL_dscale_raw, float* dL_dalpha_raw, float* dL_dcolor_raw,
                                    void* stream);
 
+/* ------------------------------------------------- neural-point map maintenance
+ * Replaces the per-frame torch bookkeeping of `NeuralPoints`:
+ *   voxel_down_sample_torch   utils/tools.py:924-967
+ *   NeuralPoints.update       model/neural_gaussians.py:214-375 (everything but the feature initialisation)
+ *   reset_local_map           model/neural_gaussians.py:378-478
+ *   assign_local_to_global    model/neural_gaussians.py:482-494
+ * Indices, masks, timestamps and table entries are bit-exact with the reference (oracle/map_cpu.py, G8 vectors).
+ * Where the reference's index_put_ meets duplicate targets the LAST sample wins (its CPU semantics), here
+ * deterministically.  Map arrays are caller-owned with room for the appended rows (capacity >= num_points + M).
+ */
+PINGS_API size_t pings_voxel_downsample_scratch_bytes(int64_t N);
+/* sample_idx[<= N] (int64): index of the point closest to its voxel centre, one per occupied voxel, ordered by the
+ * reference's linear voxel id; *count (HOST) = number of voxels.  Synchronises `stream` once. */
+PINGS_API int pings_voxel_downsample(const float* points, int64_t N, float voxel_size, void* scratch,
+                                     int64_t* sample_idx, int64_t* count, void* stream);
+PINGS_API size_t pings_map_update_scratch_bytes(int64_t M, int64_t num_points);
+/* Inserts the M voxel representatives.  table[buffer_size] int64; travel_dist NULL = no travel-distance window
+ * (temporal_local_map_on False); sample_colors / point_colors nullable together.  update_mask[M] (uint8, nullable)
+ * <- 1 where the sample became a new neural point; *num_new (HOST).  Appends rows num_points .. num_points+num_new-1
+ * of every map array (identity orientation, ts = cur_ts, certainty 0, free = !is_reliable, valid = 1, colour +
+ * colour validity) and refreshes the colour of existing points whose colour was invalid.  Synchronises once. */
+PINGS_API int pings_map_update(const float* sample_points, const float* sample_colors, int64_t M, float resolution,
+                               int64_t buffer_size, int64_t* table, int64_t num_points, const float* travel_dist,
+                               int cur_ts, float diff_travel_dist_local, int is_reliable, float* neural_points,
+                               float* point_orientations, int32_t* point_ts_create, int32_t* point_ts_update,
+                               float* point_certainties, uint8_t* free_gs_mask, uint8_t* valid_gs_mask,
+                               float* point_colors, uint8_t* valid_color_mask, void* scratch, uint8_t* update_mask,
+                               int64_t* num_new, void* stream);
+PINGS_API size_t pings_map_reset_local_scratch_bytes(int64_t num_points);
+/* local_mask / sorrounding_mask [num_points+1] (uint8, last = 1), global2local[num_points+1] (int64: rank for local
+ * points, 1 for the others — the reference's full_like(bool,-1) — and -1 for the padding entry),
+ * local_idx[num_points+1] (int64: the local rows in order, followed by the padding row num_points),
+ * *num_local (HOST).  sensor_position: DEVICE [3].  Synchronises once. */
+PINGS_API int pings_map_reset_local(int64_t num_points, const float* neural_points, const int32_t* point_ts_create,
+                                    const int32_t* point_ts_update, const float* travel_dist, int cur_ts,
+                                    int use_mid_ts, int use_travel_dist, float diff_travel_dist_local,
+                                    int diff_ts_local, const float* sensor_position, int range_filter_2d,
+                                    float local_radius, float sorrounding_radius, void* scratch, uint8_t* local_mask,
+                                    uint8_t* sorrounding_mask, int64_t* global2local, int64_t* local_idx,
+                                    int64_t* num_local, void* stream);
+/* dst[i] = src[idx[i]] / dst[idx[i]] = src[i] for rows of row_bytes bytes (any dtype). */
+PINGS_API int pings_gather_rows(const void* src, int64_t row_bytes, const int64_t* idx, int64_t n, void* dst,
+                                void* stream);
+PINGS_API int pings_scatter_rows(const void* src, int64_t row_bytes, const int64_t* idx, int64_t n, void* dst,
+                                 void* stream);
+
 #endif /* PINGS_HIP_H_ */

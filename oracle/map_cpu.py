@@ -51,6 +51,14 @@ def hash_slots(points: torch.Tensor, resolution: float, buffer_size: int) -> tor
     return h
 
 
+def _last_wins(target_idx: torch.Tensor, size: int) -> torch.Tensor:
+    """Rows of `target_idx` that survive an index_put_ in which, among duplicates, the LAST row wins (what the
+    reference's single-threaded CPU index_put_ does; torch parallelises large ones, so the rule is made explicit)."""
+    k = torch.arange(target_idx.numel(), dtype=torch.int64)
+    win = torch.full((size,), -1, dtype=torch.int64).scatter_reduce_(0, target_idx, k, reduce="amax", include_self=True)
+    return win[target_idx] == k
+
+
 def new_map(buffer_size: int, geo_dim: int, color_dim: int, resolution: float, temporal_local_map_on=True,
             use_mid_ts=False, range_filter_2d=False, local_map_radius=5.0, sorrounding_map_radius=7.0,
             diff_travel_dist_local=2.0, color_on=True) -> SimpleNamespace:
@@ -94,8 +102,10 @@ def update(m, points, colors, cur_ts: int, is_reliable: bool = True, new_geo=Non
         if sc is not None:
             ok = sc[:, 0] >= 0.0
             cm = (hidx > -1) & (m.valid_color_mask[hidx] == 0) & ok
-            m.point_colors[hidx[cm]] = sc[cm]          # duplicates: the last sample wins (CPU index_put_)
-            m.valid_color_mask[hidx[cm]] = True
+            rows = torch.nonzero(cm).flatten()
+            rows = rows[_last_wins(hidx[rows], n_old)]  # duplicates: the last sample wins (CPU index_put_)
+            m.point_colors[hidx[rows]] = sc[rows]
+            m.valid_color_mask[hidx[rows]] = True
         if m.temporal_local_map_on:
             dt = m.travel_dist[cur_ts] - m.travel_dist[m.point_ts_update[hidx].long()]
             upd = upd | (dt > m.diff_travel_dist_local)
@@ -105,7 +115,9 @@ def update(m, points, colors, cur_ts: int, is_reliable: bool = True, new_geo=Non
     n_new = added.shape[0]
     cur = m.buffer_pt_index[hv]
     cur[upd] = torch.arange(n_new, dtype=torch.int64) + n_old
-    m.buffer_pt_index[hv] = cur                          # duplicates: the last sample wins
+    slot = torch.where(hv < 0, hv + m.buffer_size, hv)
+    keep = _last_wins(slot, m.buffer_size)               # duplicates: the last sample wins
+    m.buffer_pt_index[slot[keep]] = cur[keep]
     m.neural_points = torch.cat((m.neural_points, added), 0)
     ident = torch.zeros(n_new, 4)
     ident[:, 0] = 1.0

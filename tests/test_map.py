@@ -76,3 +76,88 @@ def test_global2local_quirk_is_one_not_minus_one(golden_dir):
     st = _load(golden_dir, "slam_v025")
     g2l, lm = st["f2_global2local"], st["f2_local_mask"]
     assert g2l[-1] == -1 and (g2l[:-1][~lm[:-1]] == 1).all()      # torch.full_like(bool, -1).long()
+
+
+class _HipAdapter:
+    """pings_amd.neural_map with the oracle's call shapes."""
+
+    def __init__(self):
+        from pings_amd import neural_map as NM
+        self.NM = NM
+        self.new_map = NM.new_map
+        self.voxel_down_sample = NM.voxel_down_sample
+        self.assign_local_to_global = NM.assign_local_to_global
+
+    def update(self, m, pts, cols, ts, is_reliable=True, new_geo=None, new_color=None):
+        ratio = self.NM.update(m, pts, cols, None, None, None, cur_ts=ts, is_reliable=is_reliable, new_geo=new_geo,
+                               new_color=new_color)
+        return ratio, m._last_sample_idx, m._last_update_mask
+
+    def reset_local_map(self, m, sensor, ts):
+        self.NM.reset_local_map(m, sensor, None, ts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_map_hip_matches_reference_golden(golden_dir, name):
+    _run_frames(_load(golden_dir, name), _HipAdapter(), "cuda")
+
+
+@pytest.mark.gpu
+def test_map_product_path_rejects_host_tensors():
+    from pings_amd import _lib, neural_map as NM
+
+    with pytest.raises(_lib.PingsHipError):
+        NM.voxel_down_sample(torch.rand(100, 3), 0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("voxel,n,extent", [(0.3, 200_000, 60.0), (0.1, 400_000, 25.0)])
+def test_map_hip_matches_oracle_large_random(voxel, n, extent):
+    """200k-400k-point scans over several frames with a small table (many hash collisions): the HIP path against the
+    CPU oracle — voxel representatives, new-point decisions, table, local map, write-back — all exact."""
+    hip = _HipAdapter()
+    g = torch.Generator().manual_seed(int(voxel * 100))
+    kw = dict(temporal_local_map_on=True, use_mid_ts=True, range_filter_2d=True, local_map_radius=0.3 * extent,
+              sorrounding_map_radius=0.45 * extent, diff_travel_dist_local=0.25 * extent)
+    mc = M.new_map(400_009, 8, 4, voxel, **kw)
+    mh = hip.new_map(400_009, 8, 4, voxel, device="cuda", **kw)
+    td = torch.tensor([0.0, 0.1 * extent, 0.22 * extent, 0.5 * extent])
+    mc.travel_dist, mh.travel_dist = td, td.cuda()
+    for ts in range(3):
+        xy = (torch.rand(n, 2, generator=g) - 0.5) * extent + 0.1 * extent * ts
+        z = 2.0 * torch.sin(0.3 * xy[:, 0]) + torch.cos(0.2 * xy[:, 1]) + 0.02 * torch.randn(n, generator=g)
+        pts = torch.cat([xy, z[:, None]], 1)
+        cols = torch.rand(n, 3, generator=g)
+        cols[torch.rand(n, generator=g) < 0.3, 0] = -1.0
+        sidx_c = M.voxel_down_sample(pts, voxel)
+        sidx_h = hip.voxel_down_sample(pts.cuda(), voxel)
+        assert torch.equal(sidx_h.cpu(), sidx_c)
+        n_old = mc.neural_points.shape[0]
+        _, _, upd_c = M.update(mc, pts, cols, ts, is_reliable=(ts != 1))
+        n_new = mc.neural_points.shape[0] - n_old
+        gen2 = torch.Generator().manual_seed(ts)
+        ng, ncol = torch.randn(n_new + 1, 8, generator=gen2), torch.randn(n_new + 1, 4, generator=gen2)
+        mc.geo_features[n_old:] = ng
+        mc.color_features[n_old:] = ncol
+        _, _, upd_h = hip.update(mh, pts.cuda(), cols.cuda(), ts, is_reliable=(ts != 1), new_geo=ng, new_color=ncol)
+        assert torch.equal(upd_h.cpu(), upd_c)
+        for k in ("neural_points", "point_colors", "valid_color_mask", "free_gs_mask", "point_ts_create",
+                  "point_ts_update", "buffer_pt_index", "geo_features", "color_features", "point_orientations",
+                  "valid_gs_mask", "point_certainties"):
+            assert torch.equal(getattr(mh, k).cpu(), getattr(mc, k)), (ts, k)
+        sensor = torch.tensor([0.1 * extent * ts, 0.1 * extent * ts, 1.0])
+        M.reset_local_map(mc, sensor, ts)
+        hip.reset_local_map(mh, sensor.cuda(), ts)
+        for k in ("local_mask", "sorrounding_mask", "global2local", "local_neural_points", "local_point_orientations",
+                  "local_point_certainties", "local_point_ts_update", "local_point_colors", "local_valid_color_mask",
+                  "local_valid_gs_mask", "local_free_gs_mask", "local_geo_features", "local_color_features"):
+            assert torch.equal(getattr(mh, k).detach().cpu(), getattr(mc, k)), (ts, k)
+        for m_ in (mc, mh):
+            with torch.no_grad():
+                m_.local_geo_features += 0.25
+            m_.local_point_certainties = m_.local_point_certainties + 1.0
+        M.assign_local_to_global(mc)
+        hip.assign_local_to_global(mh)
+        for k in ("geo_features", "color_features", "point_certainties", "point_ts_update"):
+            assert torch.equal(getattr(mh, k).cpu(), getattr(mc, k)), (ts, k)
