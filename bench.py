@@ -299,6 +299,67 @@ def bench_decoder(dev, steps, warmup, n_points=125_000):
             "wall_ms_fwd_bwd_autograd": round(dt * 1e3, 4)}
 
 
+def bench_map(dev, frames=6, n_scan=1_000_000, voxel=0.1, with_cpu=True):
+    """per-frame map maintenance — voxel down-sampling + `update` (hash insert, appends) +
+    `reset_local_map` + `assign_local_to_global` on a growing map (1M-point scans of a wavy street-sized sheet,
+    0.1 m voxels, 1e8-slot table), HIP path vs the CPU oracle (the reference's torch op sequence) on the same scans."""
+    from pings_amd import neural_map as NM
+    from oracle import map_cpu as MC
+
+    kw = dict(temporal_local_map_on=True, use_mid_ts=False, range_filter_2d=True, local_map_radius=60.0,
+              sorrounding_map_radius=84.0, diff_travel_dist_local=300.0)
+    g = torch.Generator().manual_seed(5)
+    scans = []
+    for ts in range(frames):
+        xy = (torch.rand(n_scan, 2, generator=g) - 0.5) * 160.0 + torch.tensor([8.0 * ts, 0.0])
+        z = 2.0 * torch.sin(0.3 * xy[:, 0]) + torch.cos(0.2 * xy[:, 1]) + 0.02 * torch.randn(n_scan, generator=g)
+        scans.append((torch.cat([xy, z[:, None]], 1), torch.rand(n_scan, 3, generator=g),
+                      torch.tensor([8.0 * ts, 0.0, 1.5])))
+    td = torch.arange(frames + 1, dtype=torch.float32) * 8.0
+
+    def run(mod, m, device):
+        ts_ms = []
+        for ts, (pts, cols, sensor) in enumerate(scans):
+            pts, cols, sensor = pts.to(device), cols.to(device), sensor.to(device)
+            if device != "cpu":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if mod is NM:
+                NM.update(m, pts, cols, None, sensor, None, cur_ts=ts)
+                NM.assign_local_to_global(m)
+            else:
+                MC.update(m, pts, cols, ts)
+                MC.reset_local_map(m, sensor, ts)
+                MC.assign_local_to_global(m)
+            if device != "cpu":
+                torch.cuda.synchronize()
+            ts_ms.append((time.perf_counter() - t0) * 1e3)
+        return ts_ms
+
+    mh = NM.new_map(100_000_000, 32, 16, voxel, device=str(dev), **kw)
+    mh.travel_dist = td.to(dev)
+    t_hip = run(NM, mh, str(dev))
+    out = {"scan_points": n_scan, "voxel_m": voxel, "frames": frames, "map_points_final": int(mh.neural_points.shape[0]),
+           "local_points_final": int(mh.local_neural_points.shape[0]), "buffer_size": 100_000_000,
+           "ms_per_frame": [round(t, 3) for t in t_hip],
+           "Mpoints_s": round(n_scan * (frames - 1) / (sum(t_hip[1:]) * 1e-3) / 1e6, 2)}
+    del mh
+    torch.cuda.empty_cache()
+    if with_cpu:
+        mc = MC.new_map(100_000_000, 32, 16, voxel, **kw)
+        mc.travel_dist = td
+        n_cpu = 3
+        scans_cpu = scans[:n_cpu]
+        scans_full, scans[:] = list(scans), scans_cpu
+        t_cpu = run(MC, mc, "cpu")
+        scans[:] = scans_full
+        out["cpu_baseline"] = {"value": round(n_scan * (n_cpu - 1) / (sum(t_cpu[1:]) * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/map_cpu.py (reference torch op sequence), first {n_cpu} of the same scans "
+                                         f"({sum(t_cpu) / 1e3:.1f} s of CPU work; host has {os.cpu_count()} logical cores)"}
+    return out
+
+
 def cpu_baseline_sdf(npm, dec, B=131072, reps=8):
     """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores,
     same map and queries as the GPU run (tensors copied to the host)."""
@@ -502,6 +563,7 @@ def main():
             del npm, dec
             torch.cuda.empty_cache()
         decoder = bench_decoder(dev, max(args.steps, 5), max(args.warmup, 2)) if not args.no_sdf else None
+        map_maint = bench_map(dev, with_cpu=not args.no_cpu_baseline) if not args.no_sdf else None
         line = {
             "metric": "raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -515,6 +577,7 @@ def main():
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf, "decoder": decoder,
+            "map_maintenance": map_maint,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
