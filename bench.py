@@ -74,14 +74,14 @@ def pmc_traffic(stage):
     try:
         files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("pmc_traffic.json"))
         if not files:
-            return None, None
+            return None, None, None
         data = json.load(open(files[-1]))
         for name, v in data.items():
             if name.startswith(stage + "_kernel"):
-                return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root))
+                return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root)), v.get("valu_insts")
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def parse_prof(txt):
@@ -539,10 +539,15 @@ def main():
         }
         dom = max((k for k in per if k in alg), key=lambda k: per[k])
         achieved = alg[dom] / (per[dom] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src, valu_insts = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
+                    # the blend kernels are vector-ALU bound: wave-instructions issued per launch (SQ_INSTS_VALU of the
+                    # committed PMC pass) / measured time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op
+                    "valu": None if not valu_insts else {
+                        "wave_insts": int(valu_insts), "achieved_Ginst_s": round(valu_insts / (per[dom] * 1e-3) / 1e9, 1),
+                        "peak_Ginst_s": 1228.8, "frac": round(valu_insts / (per[dom] * 1e-3) / 1228.8e9, 4)},
                     "avg_ms": round(per[dom], 4), "algorithmic_bytes": int(alg[dom]),
                     "note": "blend kernels are fp32-VALU bound (LDS-broadcast records, ~250 flop per "
                             "fetched byte); see DESIGN.md"}

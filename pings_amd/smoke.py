@@ -108,9 +108,35 @@ def _mlp(dev):
     print("smoke: MFMA decoder MLP ok")
 
 
+def _map(dev):
+    """Two frames of map maintenance (voxel down-sampling, update, reset_local_map) against the CPU oracle, exact."""
+    from oracle import map_cpu as MC
+    from pings_amd import neural_map as NM
+
+    g = torch.Generator().manual_seed(4)
+    kw = dict(temporal_local_map_on=True, local_map_radius=6.0, sorrounding_map_radius=9.0, diff_travel_dist_local=5.0)
+    mc, mh = MC.new_map(50021, 8, 4, 0.2, **kw), NM.new_map(50021, 8, 4, 0.2, device=str(dev), **kw)
+    mc.travel_dist = torch.tensor([0.0, 1.0, 2.0])
+    mh.travel_dist = mc.travel_dist.to(dev)
+    for ts in range(2):
+        pts = (torch.rand(20000, 3, generator=g) - 0.5) * torch.tensor([20.0, 20.0, 1.0]) + ts
+        cols = torch.rand(20000, 3, generator=g)
+        MC.update(mc, pts, cols, ts)
+        NM.update(mh, pts.to(dev), cols.to(dev), None, None, None, cur_ts=ts,
+                  new_geo=torch.zeros(1), new_color=torch.zeros(1))
+        sensor = torch.tensor([float(ts), float(ts), 0.0])
+        MC.reset_local_map(mc, sensor, ts)
+        NM.reset_local_map(mh, sensor.to(dev), None, ts)
+        for k in ("neural_points", "buffer_pt_index", "point_ts_create", "global2local", "local_neural_points"):
+            assert torch.equal(getattr(mh, k).cpu(), getattr(mc, k)), k
+    print("smoke: map maintenance ok,", int(mh.neural_points.shape[0]), "neural points,",
+          int(mh.local_neural_points.shape[0]), "local")
+
+
 def run() -> None:
     dev = torch.device("cuda:0")
     _ssim(dev)
     _raster(dev)
     _sdf(dev)
     _mlp(dev)
+    _map(dev)

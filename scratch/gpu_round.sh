@@ -16,7 +16,10 @@ cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof.log 2>&1; echo "prof rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/pmc_sq -o q -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdf > $O/pmc_sq.log 2>&1; echo "pmc sq rc=$?"
 cd $R
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --single-device --no-sdf --no-cpu-baseline > $O/bench_2rank_gloo.log 2>&1; echo "2-rank rehearsal rc=$?"
+tail -c 400 $O/bench_2rank_gloo.log
 find $O -type f -size +12M -delete
 du -sh $O
 ls -la $O $O/prof 2>/dev/null | head -30
