@@ -389,4 +389,19 @@ PINGS_API int pings_gather_rows(const void* src, int64_t row_bytes, const int64_
 PINGS_API int pings_scatter_rows(const void* src, int64_t row_bytes, const int64_t* idx, int64_t n, void* dst,
                                  void* stream);
 
+/* ------------------------------------------------------------ depth2normal
+ * Replaces `depth2normal(depth, mask, camera, img_scale)` (gaussian_splatting/utils/point_utils.py:83-149) as `render`
+ * uses it (gaussian_renderer/__init__.py:330-335), with the multiplication by the detached rendered alpha fused in:
+ *   normal[3,H,W] = normalize(sum of the four neighbour cross products of the un-projected depth) * mask * alpha.
+ * Visibility: `mask[H,W]` (uint8) if given, else `alpha > min_alpha`; `alpha` NULL = no weighting.  cx, cy, fx, fy are
+ * the principal point / focal lengths in pixels of the (down-scaled) image.  Gradient flows to the depth only (mask
+ * and alpha are detached in the reference). */
+PINGS_API int pings_depth2normal_forward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
+                                         float cx, float cy, float fx, float fy, float min_alpha, float* normal,
+                                         void* stream);
+PINGS_API size_t pings_depth2normal_backward_scratch_bytes(int H, int W);
+PINGS_API int pings_depth2normal_backward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
+                                          float cx, float cy, float fx, float fy, float min_alpha,
+                                          const float* dL_dnormal, void* scratch, float* dL_ddepth, void* stream);
+
 #endif /* PINGS_HIP_H_ */

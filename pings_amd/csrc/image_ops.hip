@@ -1,0 +1,213 @@
+// Image-space operators of `render` (gaussian_splatting/gaussian_renderer/__init__.py:330-337), for gfx950.
+//
+// depth2normal (gaussian_splatting/utils/point_utils.py:83-149): camera-frame normals from the rendered depth map.
+// Every pixel is un-projected to P = ((u - cx) d / fx, (v - cy) d / fy, d), the four neighbour differences
+// (replicate padding, each multiplied by the neighbour's visibility mask) are crossed pairwise, the four cross
+// products are summed and normalised, and the result is multiplied by the centre's mask and — fused here, `render`
+// does it right after (:335) — by the detached rendered alpha.  The reference runs ~25 full-frame torch kernels for
+// the forward pass and autograd doubles that; here it is one stencil kernel forward and two backward
+// (per-centre adjoints of the five stencil points, then a gather of the five contributions every pixel receives:
+// no atomics, bitwise reproducible).  HBM bound: forward 8 B in + 12 B out per pixel, backward 20 B in + 60 B
+// scratch write + 60 B scratch read + 4 B out.
+#include "common.hpp"
+
+namespace {
+
+struct D2N {
+  int H, W;
+  float cx, cy, ifx, ify, min_alpha;
+  const float* depth;
+  const float* alpha;   // nullable: weight (detached rendered alpha) and, with `mask` null, the visibility test
+  const uint8_t* mask;  // nullable: explicit visibility mask (depth2normal's second argument)
+};
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ inline bool visible(const D2N& a, int x, int y) {
+  const size_t i = (size_t)y * a.W + x;
+  return a.mask ? a.mask[i] != 0 : a.alpha[i] > a.min_alpha;
+}
+
+__device__ inline void unproject(const D2N& a, int x, int y, float& px, float& py, float& pz) {
+  const float d = a.depth[(size_t)y * a.W + x];
+  px = (((float)x - a.cx) * d) * a.ifx;   // (w - cx) * camD, then @ Kinv^T  (point_utils.py:101-113)
+  py = (((float)y - a.cy) * d) * a.ify;
+  pz = d;
+}
+
+struct Stencil {
+  float c[3], u[3], l[3], b[3], r[3];  // masked centre and the four masked differences
+  float mu, ml, mb, mr, mc;
+};
+
+__device__ inline Stencil stencil(const D2N& a, int x, int y) {
+  Stencil s;
+  const int xl = clampi(x - 1, 0, a.W - 1), xr = clampi(x + 1, 0, a.W - 1);
+  const int yu = clampi(y - 1, 0, a.H - 1), yb = clampi(y + 1, 0, a.H - 1);
+  s.mc = visible(a, x, y) ? 1.f : 0.f;
+  s.mu = visible(a, x, yu) ? 1.f : 0.f;
+  s.ml = visible(a, xl, y) ? 1.f : 0.f;
+  s.mb = visible(a, x, yb) ? 1.f : 0.f;
+  s.mr = visible(a, xr, y) ? 1.f : 0.f;
+  float p[3];
+  unproject(a, x, y, p[0], p[1], p[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.c[k] = p[k] * s.mc;
+  unproject(a, x, yu, p[0], p[1], p[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.u[k] = (p[k] - s.c[k]) * s.mu;
+  unproject(a, xl, y, p[0], p[1], p[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.l[k] = (p[k] - s.c[k]) * s.ml;
+  unproject(a, x, yb, p[0], p[1], p[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.b[k] = (p[k] - s.c[k]) * s.mb;
+  unproject(a, xr, y, p[0], p[1], p[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s.r[k] = (p[k] - s.c[k]) * s.mr;
+  return s;
+}
+
+__device__ inline void cross(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// n = u x l + r x u + b x r + l x b
+__device__ inline void normal_sum(const Stencil& s, float n[3]) {
+  float t[3];
+  cross(s.u, s.l, n);
+  cross(s.r, s.u, t); n[0] += t[0]; n[1] += t[1]; n[2] += t[2];
+  cross(s.b, s.r, t); n[0] += t[0]; n[1] += t[1]; n[2] += t[2];
+  cross(s.l, s.b, t); n[0] += t[0]; n[1] += t[1]; n[2] += t[2];
+}
+
+__global__ __launch_bounds__(256) void d2n_fwd_kernel(D2N a, float* __restrict__ out) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.W || y >= a.H) return;
+  const Stencil s = stencil(a, x, y);
+  float n[3];
+  normal_sum(s, n);
+  const float nrm = fmaxf(sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]), 1e-12f);  // F.normalize eps
+  const size_t i = (size_t)y * a.W + x, HW = (size_t)a.H * a.W;
+  const float w = s.mc * (a.alpha ? a.alpha[i] : 1.f);
+  out[i] = n[0] / nrm * w;
+  out[HW + i] = n[1] / nrm * w;
+  out[2 * HW + i] = n[2] / nrm * w;
+}
+
+// Pass 1: per centre pixel, dL/d(un-projected point) of the centre and of its four stencil neighbours
+// (15 floats, planar [15][H][W]).
+__global__ __launch_bounds__(256) void d2n_bwd_stencil_kernel(D2N a, const float* __restrict__ g_out,
+                                                              float* __restrict__ adj) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.W || y >= a.H) return;
+  const size_t i = (size_t)y * a.W + x, HW = (size_t)a.H * a.W;
+  const Stencil s = stencil(a, x, y);
+  float n[3];
+  normal_sum(s, n);
+  const float nn = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+  const float w = s.mc * (a.alpha ? a.alpha[i] : 1.f);
+  float g[3] = {g_out[i] * w, g_out[HW + i] * w, g_out[2 * HW + i] * w};
+  float gn[3];
+  if (nn > 1e-12f) {  // d(n / |n|) = (I - nh nh^T) / |n|
+    const float inv = 1.f / nn;
+    const float h0 = n[0] * inv, h1 = n[1] * inv, h2 = n[2] * inv;
+    const float dot = (h0 * g[0] + h1 * g[1]) + h2 * g[2];
+    gn[0] = (g[0] - h0 * dot) * inv;
+    gn[1] = (g[1] - h1 * dot) * inv;
+    gn[2] = (g[2] - h2 * dot) * inv;
+  } else {            // clamp_min(eps) active: n / eps
+    gn[0] = g[0] / 1e-12f; gn[1] = g[1] / 1e-12f; gn[2] = g[2] / 1e-12f;
+  }
+  // n = u x l + r x u + b x r + l x b.  d(a x b) . gn:  wrt a = b x gn,  wrt b = gn x a
+  float gu[3], gl[3], gb[3], gr[3], t[3];
+  cross(s.l, gn, gu); cross(gn, s.r, t);                      // u: first of (u x l), second of (r x u)
+  gu[0] += t[0]; gu[1] += t[1]; gu[2] += t[2];
+  cross(gn, s.u, gl); cross(s.b, gn, t);                      // l: second of (u x l), first of (l x b)
+  gl[0] += t[0]; gl[1] += t[1]; gl[2] += t[2];
+  cross(s.r, gn, gb); cross(gn, s.l, t);                      // b: first of (b x r), second of (l x b)
+  gb[0] += t[0]; gb[1] += t[1]; gb[2] += t[2];
+  cross(s.u, gn, gr); cross(gn, s.b, t);                      // r: first of (r x u), second of (b x r)
+  gr[0] += t[0]; gr[1] += t[1]; gr[2] += t[2];
+  // differences: u = (P_u - c) m_u, c = P_c m_c
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float du = gu[k] * s.mu, dl = gl[k] * s.ml, db = gb[k] * s.mb, dr = gr[k] * s.mr;
+    adj[(size_t)(0 + k) * HW + i] = -(du + dl + db + dr) * s.mc;  // to the centre's own point
+    adj[(size_t)(3 + k) * HW + i] = du;                           // to the upper neighbour's point
+    adj[(size_t)(6 + k) * HW + i] = dl;
+    adj[(size_t)(9 + k) * HW + i] = db;
+    adj[(size_t)(12 + k) * HW + i] = dr;
+  }
+}
+
+// Pass 2: every pixel collects what the stencils that reference it sent (its own centre term, and the up / left /
+// bottom / right terms of the pixels whose clamped neighbour it is), then chains through P = (ax d, ay d, d).
+__global__ __launch_bounds__(256) void d2n_bwd_gather_kernel(D2N a, const float* __restrict__ adj,
+                                                             float* __restrict__ g_depth) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= a.W || y >= a.H) return;
+  const size_t HW = (size_t)a.H * a.W;
+  float gp[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = adj[(size_t)k * HW + (size_t)y * a.W + x];
+    // pixel (x, y) is the UPPER neighbour of (x, y+1); with replicate padding row 0 is also its own upper neighbour
+    if (y + 1 < a.H) v += adj[(size_t)(3 + k) * HW + (size_t)(y + 1) * a.W + x];
+    if (y == 0) v += adj[(size_t)(3 + k) * HW + (size_t)y * a.W + x];
+    if (x + 1 < a.W) v += adj[(size_t)(6 + k) * HW + (size_t)y * a.W + x + 1];       // LEFT neighbour of (x+1, y)
+    if (x == 0) v += adj[(size_t)(6 + k) * HW + (size_t)y * a.W + x];
+    if (y >= 1) v += adj[(size_t)(9 + k) * HW + (size_t)(y - 1) * a.W + x];          // BOTTOM neighbour of (x, y-1)
+    if (y == a.H - 1) v += adj[(size_t)(9 + k) * HW + (size_t)y * a.W + x];
+    if (x >= 1) v += adj[(size_t)(12 + k) * HW + (size_t)y * a.W + x - 1];           // RIGHT neighbour of (x-1, y)
+    if (x == a.W - 1) v += adj[(size_t)(12 + k) * HW + (size_t)y * a.W + x];
+    gp[k] = v;
+  }
+  const float ax = ((float)x - a.cx) * a.ifx, ay = ((float)y - a.cy) * a.ify;
+  g_depth[(size_t)y * a.W + x] = (gp[0] * ax + gp[1] * ay) + gp[2];
+}
+
+int fill(D2N& a, const float* depth, const float* alpha, const uint8_t* mask, int H, int W, float cx, float cy,
+         float fx, float fy, float min_alpha) {
+  PINGS_ARG_CHECK(H > 0 && W > 0 && depth, "bad image");
+  PINGS_ARG_CHECK(alpha || mask, "need a visibility mask or the rendered alpha");
+  PINGS_ARG_CHECK(fx != 0.f && fy != 0.f, "zero focal length");
+  a.H = H; a.W = W; a.cx = cx; a.cy = cy; a.ifx = 1.0f / fx; a.ify = 1.0f / fy; a.min_alpha = min_alpha;
+  a.depth = depth; a.alpha = alpha; a.mask = mask;
+  return PINGS_OK;
+}
+
+}  // namespace
+
+PINGS_API int pings_depth2normal_forward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
+                                         float cx, float cy, float fx, float fy, float min_alpha, float* normal,
+                                         void* stream) {
+  D2N a;
+  if (int rc = fill(a, depth, alpha, mask, H, W, cx, cy, fx, fy, min_alpha)) return rc;
+  PINGS_ARG_CHECK(normal != nullptr, "null output");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("depth2normal_fwd", st);
+  d2n_fwd_kernel<<<dim3(pings::ceil_div(W, 32), pings::ceil_div(H, 8)), 256, 0, st>>>(a, normal);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API size_t pings_depth2normal_backward_scratch_bytes(int H, int W) { return (size_t)15 * H * W * sizeof(float); }
+
+PINGS_API int pings_depth2normal_backward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
+                                          float cx, float cy, float fx, float fy, float min_alpha,
+                                          const float* dL_dnormal, void* scratch, float* dL_ddepth, void* stream) {
+  D2N a;
+  if (int rc = fill(a, depth, alpha, mask, H, W, cx, cy, fx, fy, min_alpha)) return rc;
+  PINGS_ARG_CHECK(dL_dnormal && scratch && dL_ddepth, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("depth2normal_bwd", st);
+  const dim3 grid(pings::ceil_div(W, 32), pings::ceil_div(H, 8));
+  d2n_bwd_stencil_kernel<<<grid, 256, 0, st>>>(a, dL_dnormal, reinterpret_cast<float*>(scratch));
+  PINGS_LAUNCH_CHECK();
+  d2n_bwd_gather_kernel<<<grid, 256, 0, st>>>(a, reinterpret_cast<const float*>(scratch), dL_ddepth);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}

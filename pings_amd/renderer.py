@@ -20,36 +20,17 @@ import torch
 
 from . import _lib
 from . import decoder as _dec
+from . import image_ops as _img
 from . import rasterizer as _rast
 from . import spawn as _spawn
 
 
 # ------------------------------------------------------------------ depth -> normal (point_utils.py:83-149)
-def depth2normal(depth: torch.Tensor, mask: torch.Tensor, camera, img_scale: int = 1) -> torch.Tensor:
-    """Camera-frame normals from a rendered depth map by crossing the four neighbour differences
-    (gaussian_splatting/utils/point_utils.py:83-149).  depth, mask: [1,H,W]; returns [3,H,W]."""
-    _, H, W = depth.shape
-    dev, dt = depth.device, torch.float32
-    v, u = torch.meshgrid(torch.arange(H, device=dev, dtype=dt), torch.arange(W, device=dev, dtype=dt),
-                          indexing="ij")
-    cx = camera.prcppoint[0] * camera.image_width / img_scale
-    cy = camera.prcppoint[1] * camera.image_height / img_scale
-    d = depth[0]
-    x = (u - cx) * d / (camera.fx / img_scale)
-    y = (v - cy) * d / (camera.fy / img_scale)
-    p = torch.stack((x, y, d), dim=-1)                                   # H, W, 3
-    pp = torch.nn.functional.pad(p.permute(2, 0, 1)[None], (1, 1, 1, 1), mode="replicate")[0].permute(1, 2, 0)
-    mm = torch.nn.functional.pad(mask.to(dt)[None], (1, 1, 1, 1), mode="replicate")[0, 0].to(torch.bool)
-    mc = mm[1:-1, 1:-1, None]
-    c = pp[1:-1, 1:-1] * mc
-    up = (pp[:-2, 1:-1] - c) * mm[:-2, 1:-1, None]
-    lf = (pp[1:-1, :-2] - c) * mm[1:-1, :-2, None]
-    dn = (pp[2:, 1:-1] - c) * mm[2:, 1:-1, None]
-    rt = (pp[1:-1, 2:] - c) * mm[1:-1, 2:, None]
-    n = (torch.linalg.cross(up, lf) + torch.linalg.cross(rt, up) + torch.linalg.cross(dn, rt)
-         + torch.linalg.cross(lf, dn))
-    n = torch.nn.functional.normalize(n, dim=-1)
-    return (n * mc).permute(2, 0, 1)
+def depth2normal(depth: torch.Tensor, mask: torch.Tensor, camera, img_scale: int = 1, weight=None) -> torch.Tensor:
+    """Camera-frame normals from a rendered depth map (gaussian_splatting/utils/point_utils.py:83-149) on the HIP
+    device (csrc/image_ops.hip).  depth, mask: [1,H,W]; returns [3,H,W].  `weight` ([1,H,W], detached) is multiplied
+    in, which is what `render` does right after (:335)."""
+    return _img.depth2normal(depth, mask, camera, img_scale, weight)
 
 
 # ------------------------------------------------------------------ spawn
@@ -280,7 +261,7 @@ def render(viewpoint_camera,
         mask_vis = alpha_detached > min_alpha
         d2n = None
         if d2n_on:
-            d2n = depth2normal(rendered_depth, mask_vis, viewpoint_camera, img_scale=img_scale) * alpha_detached
+            d2n = depth2normal(rendered_depth, mask_vis, viewpoint_camera, img_scale=img_scale, weight=alpha_detached)
         results.update({"rend_normal": rendered_normal, "surf_depth": rendered_depth, "rend_alpha": rendered_alpha,
                         "surf_normal": d2n, "rend_dist": None, "viewspace_points": screenspace_points,
                         "visibility_filter": radii > 0, "radii": radii, "contributions": contributions})
@@ -291,7 +272,7 @@ def render(viewpoint_camera,
         rendered_depth[mask_vis] /= alpha_detached[mask_vis]               # in place, like :430
         d2n = None
         if d2n_on:
-            d2n = depth2normal(rendered_depth, mask_vis, viewpoint_camera, img_scale=img_scale) * alpha_detached
+            d2n = depth2normal(rendered_depth, mask_vis, viewpoint_camera, img_scale=img_scale, weight=alpha_detached)
         rendered_depth[~mask_vis] = 0.0
         results.update({"rend_normal": None, "surf_depth": rendered_depth, "rend_alpha": rendered_alpha,
                         "surf_normal": d2n, "rend_dist": None, "viewspace_points": screenspace_points,

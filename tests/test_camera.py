@@ -1,5 +1,5 @@
-"""Camera conventions (G6/G7): pings_amd.camera, the oracle's look_at_camera and renderer.depth2normal
-against vectors produced by the reference's CamImage / depth2normal / update_pose."""
+"""Camera conventions (G6/G7): pings_amd.camera, the oracle's look_at_camera and depth2normal (CPU oracle and
+HIP kernel) against vectors produced by the reference's CamImage / depth2normal / update_pose."""
 import numpy as np
 import pytest
 import torch
@@ -7,7 +7,7 @@ import torch
 from conftest import rel_err
 from oracle import raster_cpu as R
 from pings_amd.camera import Camera
-from pings_amd.renderer import depth2normal
+from oracle.d2n_cpu import depth2normal
 
 CASES = ["centered", "offcentre"]
 
@@ -44,6 +44,51 @@ def test_depth2normal_matches_reference(golden_dir, name):
     cam = Camera(W, H, K[0, 0], K[1, 1], K[0, 2], K[1, 2], device="cpu", cam_pose=torch.from_numpy(st["pose"]))
     n = depth2normal(torch.from_numpy(st["d2n_depth"]), torch.from_numpy(st["d2n_mask"]), cam, img_scale=2)
     assert rel_err(n, torch.from_numpy(st["d2n_normal"])) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_depth2normal_hip_matches_reference(golden_dir, name):
+    from pings_amd.renderer import depth2normal as d2n_hip
+
+    st = _load(golden_dir, name)
+    W, H, K = int(st["W"]), int(st["H"]), st["K"]
+    cam = Camera(W, H, K[0, 0], K[1, 1], K[0, 2], K[1, 2], device="cuda", cam_pose=torch.from_numpy(st["pose"]))
+    n = d2n_hip(torch.from_numpy(st["d2n_depth"]).cuda(), torch.from_numpy(st["d2n_mask"]).cuda(), cam, img_scale=2)
+    assert rel_err(n, torch.from_numpy(st["d2n_normal"])) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(37, 53), (1, 9), (64, 64), (270, 481)])
+def test_depth2normal_hip_forward_backward_vs_oracle(size):
+    """Random depth with holes in the visibility mask, alpha weighting, odd sizes: forward and the gradient w.r.t. the
+    depth against the fp64 autograd of the oracle (tolerance 1e-4 rel, north_star)."""
+    from pings_amd.renderer import depth2normal as d2n_hip
+
+    H, W = size
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    depth = (3.0 + 0.02 * xx + 0.5 * torch.sin(0.2 * yy) + 0.05 * torch.rand(H, W, generator=g, dtype=torch.float64))[None]
+    alpha = torch.rand(1, H, W, generator=g, dtype=torch.float64)
+    mask = alpha > 0.15
+    cam = Camera(W, H, 0.8 * W + 3.0, 0.9 * W, 0.47 * W, 0.52 * H, device="cpu", cam_pose=torch.eye(4, dtype=torch.float64))
+    gout = torch.randn(3, H, W, generator=g, dtype=torch.float64)
+    d_ref = depth.clone().requires_grad_(True)
+    n_ref = depthnormal_oracle(d_ref, mask, cam) * alpha
+    (g_ref,) = torch.autograd.grad((n_ref * gout).sum(), d_ref)
+    d_hip = depth.float().cuda().requires_grad_(True)
+    n_hip = d2n_hip(d_hip, mask.cuda(), cam, 1, weight=alpha.float().cuda())
+    (g_hip,) = torch.autograd.grad((n_hip * gout.float().cuda()).sum(), d_hip)
+    assert rel_err(n_hip, n_ref) <= 1e-4
+    assert rel_err(g_hip, g_ref) <= 1e-4
+    # run to run bitwise reproducible (no atomics)
+    (g_hip2,) = torch.autograd.grad((d2n_hip(d_hip, mask.cuda(), cam, 1, weight=alpha.float().cuda())
+                                     * gout.float().cuda()).sum(), d_hip)
+    assert torch.equal(g_hip, g_hip2)
+
+
+def depthnormal_oracle(depth, mask, cam):
+    return depth2normal(depth, mask, cam, img_scale=1)
 
 
 @pytest.mark.parametrize("name", CASES)
