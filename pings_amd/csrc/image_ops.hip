@@ -131,15 +131,21 @@ __global__ __launch_bounds__(256) void d2n_bwd_stencil_kernel(D2N a, const float
   gb[0] += t[0]; gb[1] += t[1]; gb[2] += t[2];
   cross(s.u, gn, gr); cross(gn, s.b, t);                      // r: first of (r x u), second of (b x r)
   gr[0] += t[0]; gr[1] += t[1]; gr[2] += t[2];
-  // differences: u = (P_u - c) m_u, c = P_c m_c
+  // differences: u = (P_u - c) m_u, c = P_c m_c.  At the image border the replicate padding makes a neighbour the
+  // pixel itself: its two contributions (+d to the neighbour, -d m_c to the centre) land on the same point and are
+  // folded here into d (1 - m_c).  Left separate they are +-1e11 (n = 0 there, so the normalisation divides by its
+  // 1e-12 floor) and swallow every other term of that pixel in fp32.
+  const bool su = y == 0, sl = x == 0, sb = y == a.H - 1, sr = x == a.W - 1;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float du = gu[k] * s.mu, dl = gl[k] * s.ml, db = gb[k] * s.mb, dr = gr[k] * s.mr;
-    adj[(size_t)(0 + k) * HW + i] = -(du + dl + db + dr) * s.mc;  // to the centre's own point
-    adj[(size_t)(3 + k) * HW + i] = du;                           // to the upper neighbour's point
-    adj[(size_t)(6 + k) * HW + i] = dl;
-    adj[(size_t)(9 + k) * HW + i] = db;
-    adj[(size_t)(12 + k) * HW + i] = dr;
+    const float other = (su ? 0.f : du) + (sl ? 0.f : dl) + (sb ? 0.f : db) + (sr ? 0.f : dr);
+    const float self = (su ? du : 0.f) + (sl ? dl : 0.f) + (sb ? db : 0.f) + (sr ? dr : 0.f);
+    adj[(size_t)(0 + k) * HW + i] = self * (1.f - s.mc) - other * s.mc;  // to the centre's own point
+    adj[(size_t)(3 + k) * HW + i] = su ? 0.f : du;                       // to the upper neighbour's point
+    adj[(size_t)(6 + k) * HW + i] = sl ? 0.f : dl;
+    adj[(size_t)(9 + k) * HW + i] = sb ? 0.f : db;
+    adj[(size_t)(12 + k) * HW + i] = sr ? 0.f : dr;
   }
 }
 
@@ -154,15 +160,11 @@ __global__ __launch_bounds__(256) void d2n_bwd_gather_kernel(D2N a, const float*
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float v = adj[(size_t)k * HW + (size_t)y * a.W + x];
-    // pixel (x, y) is the UPPER neighbour of (x, y+1); with replicate padding row 0 is also its own upper neighbour
+    // pixel (x, y) is the UPPER neighbour of (x, y+1), ... (self-references at the border were folded in pass 1)
     if (y + 1 < a.H) v += adj[(size_t)(3 + k) * HW + (size_t)(y + 1) * a.W + x];
-    if (y == 0) v += adj[(size_t)(3 + k) * HW + (size_t)y * a.W + x];
     if (x + 1 < a.W) v += adj[(size_t)(6 + k) * HW + (size_t)y * a.W + x + 1];       // LEFT neighbour of (x+1, y)
-    if (x == 0) v += adj[(size_t)(6 + k) * HW + (size_t)y * a.W + x];
     if (y >= 1) v += adj[(size_t)(9 + k) * HW + (size_t)(y - 1) * a.W + x];          // BOTTOM neighbour of (x, y-1)
-    if (y == a.H - 1) v += adj[(size_t)(9 + k) * HW + (size_t)y * a.W + x];
     if (x >= 1) v += adj[(size_t)(12 + k) * HW + (size_t)y * a.W + x - 1];           // RIGHT neighbour of (x-1, y)
-    if (x == a.W - 1) v += adj[(size_t)(12 + k) * HW + (size_t)y * a.W + x];
     gp[k] = v;
   }
   const float ax = ((float)x - a.cx) * a.ifx, ay = ((float)y - a.cy) * a.ify;
