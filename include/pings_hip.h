@@ -115,13 +115,15 @@ PINGS_API size_t pings_raster_image_bytes(int image_height, int image_width);
  * Writes radii[P] (int32, 0 = culled) and *num_instances (HOST int64: number of
  * (Gaussian, tile) pairs that can still reach a pixel: pairs behind the depth rank at which a
  * conservative bound proves every pixel of the tile saturated are never created; set
- * PINGS_RASTER_OCCLUSION=0 in the environment to keep them all).  Synchronises `stream` once to
- * return that count. */
+ * PINGS_RASTER_OCCLUSION=0 in the environment to keep them all) and *footprint_class (HOST: 1 = footprints of a few
+ * tiles, 2 = of many tiles; hand it unchanged to pings_raster_render / pings_raster_backward, which pick their blend
+ * kernels by it: 1 -> one pixel per lane forward, Gaussian-per-lane wave scans backward; 2 -> two pixels per lane,
+ * pixel-per-lane backward).  Synchronises `stream` once to return the two. */
 PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, const float* means3D,
                                       const float* colors, const float* opacities,
                                       const float* scales, const float* rotations,
                                       void* geom_blob, int32_t* radii, int64_t* num_instances,
-                                      void* stream);
+                                      int32_t* footprint_class, void* stream);
 
 /* Stage 2: instance binning (stable tile sort) and per-tile alpha blending.
  * Outputs are planar [C,H,W].  out_normal may be NULL in 3DGS mode.  `per_gaussian`
@@ -132,7 +134,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                                   void* geom_blob, void* binning_blob, void* image_blob,
                                   float* out_color, float* out_normal,
                                   float* out_depth, float* out_alpha, void* per_gaussian,
-                                  void* stream);
+                                  int footprint_class, void* stream);
 
 /* Scratch bytes pings_raster_backward needs (an upper bound in the instance count: the
  * gradient rows of the instances that actually blended are a data-dependent subset). */
@@ -155,7 +157,8 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
                                     const float* dL_ddepth, const float* dL_dalpha,
                                     void* bwd_blob, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
-                                    float* dL_drotations, float* dL_dtau, void* stream);
+                                    float* dL_drotations, float* dL_dtau, int footprint_class,
+                                    void* stream);
 
 /* Debug / parity taps (tests only): copies of the sorted instance list and the
  * per-tile ranges out of the binning blob, and per-pixel state out of the image blob. */

@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "raster_common.hpp"
 
@@ -344,6 +345,250 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- blend backward, Gaussian-per-lane ("wave64 scan")
+// The kernel above puts PIXELS on the lanes: the 16 gradient terms of a record then have to be summed over the wave
+// for every record (a 16 x 64 reduce-scatter, ~60 of the ~250 instructions of an iteration), and eight blend
+// channels are walked per pixel.  Here RECORDS are on the lanes.  One wave owns one 8x8 quadrant of a tile and walks
+// the tile list back to front; the records that blended something in this quadrant (the forward pass left a 4-bit
+// quadrant mask per instance) are compacted, 64 at a time, onto the lanes — lane 0 the rearmost.  For each of the
+// quadrant's 64 pixels (uniform across the wave) every lane evaluates its record's alpha; the transmittance in
+// front of each record is the pixel's running transmittance divided by an inclusive PREFIX PRODUCT of (1 - alpha)
+// over the lanes, and the colour / normal / depth blended behind it collapses, after the dot product with the
+// pixel's upstream gradient, into an exclusive PREFIX SUM of one scalar (w s): two DPP wave scans per pixel replace
+// the per-record reduction, and the 16 gradient terms simply accumulate in the lane's registers over the 64
+// pixels.  Each lane stores its 64-byte row once per (instance, quadrant); rows of one Gaussian stay contiguous and
+// are summed by the same per-Gaussian kernels.  Waves never synchronise with each other; pixels that finished
+// before the chunk are skipped for the whole wave.  Bitwise reproducible (fixed pixel order per lane).
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ inline float wave_incl_scan_mul(float x) {
+  x *= dpp_f<0x111, 0xf>(1.f, x);  // row_shr:1
+  x *= dpp_f<0x112, 0xf>(1.f, x);  // row_shr:2
+  x *= dpp_f<0x114, 0xf>(1.f, x);  // row_shr:4
+  x *= dpp_f<0x118, 0xf>(1.f, x);  // row_shr:8
+  x *= dpp_f<0x142, 0xa>(1.f, x);  // row_bcast:15 -> rows 1, 3
+  x *= dpp_f<0x143, 0xc>(1.f, x);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+__device__ inline float wave_incl_scan_add(float x) {
+  x += dpp_f<0x111, 0xf>(0.f, x);
+  x += dpp_f<0x112, 0xf>(0.f, x);
+  x += dpp_f<0x114, 0xf>(0.f, x);
+  x += dpp_f<0x118, 0xf>(0.f, x);
+  x += dpp_f<0x142, 0xa>(0.f, x);
+  x += dpp_f<0x143, 0xc>(0.f, x);
+  return x;
+}
+
+// value of lane - 1 (lane 0 gets `first`)
+__device__ inline float wave_shr1(float x, float first) { return dpp_f<0x138, 0xf>(first, x); }
+
+struct PopOp {
+  __host__ __device__ uint32_t operator()(const uint8_t& m) const { return (uint32_t)__builtin_popcount((unsigned)m & 15u); }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
+    BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+    const uint8_t* __restrict__ qmask, const uint32_t* __restrict__ cidx, float* __restrict__ rows) {
+  __shared__ float4 sPix[64][4];  // {T, R, last, coefT} {gC0, gC1, gC2, gD} {gN0, gN1, gN2, px} {py, rx, ry, -}
+  __shared__ int sQe[128];        // queue of relevant list entries, back to front
+  __shared__ uint32_t sQs[128];   // their instance slots
+
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
+  const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
+  const size_t HW = (size_t)p.W * p.H;
+
+  uint32_t last = 0;
+  {
+    float T = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gD = 0.f, coefT = 0.f;
+    float rx = 0.f, ry = 0.f;
+    if (MODE == MODE_SURFEL) {
+      const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+      const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+      rx = ((float)pix_x - cxp) / p.fx;
+      ry = ((float)pix_y - cyp) / p.fy;
+    }
+    if (pix_x < p.W && pix_y < p.H) {
+      const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+      last = n_contrib[pix_id];
+      const float T_final = final_T[pix_id];
+      T = T_final;
+      if (dL_dcolor) {
+        gC0 = dL_dcolor[pix_id];
+        gC1 = dL_dcolor[HW + pix_id];
+        gC2 = dL_dcolor[2 * HW + pix_id];
+      }
+      float gA = dL_dalpha ? dL_dalpha[pix_id] : 0.f;
+      const float gDo = dL_ddepth ? dL_ddepth[pix_id] : 0.f;
+      if (MODE == MODE_SURFEL) {
+        if (dL_dnormal) {
+          gN0 = dL_dnormal[pix_id];
+          gN1 = dL_dnormal[HW + pix_id];
+          gN2 = dL_dnormal[2 * HW + pix_id];
+        }
+        const float A = 1.0f - T_final;
+        if (A > DEPTH_ALPHA_EPS) {
+          gD = gDo / A;
+          gA -= gDo * out_depth[pix_id] / A;
+        }
+      } else {
+        gD = gDo;
+      }
+      const float bgdot = (p.bg[0] * gC0 + p.bg[1] * gC1) + p.bg[2] * gC2;
+      coefT = (gA - bgdot) * T_final;
+    }
+    sPix[lane][0] = make_float4(T, 0.f, __uint_as_float(last), coefT);
+    sPix[lane][1] = make_float4(gC0, gC1, gC2, gD);
+    sPix[lane][2] = make_float4(gN0, gN1, gN2, (float)pix_x);
+    sPix[lane][3] = make_float4((float)pix_y, rx, ry, 0.f);
+  }
+  uint32_t m = last;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  int pos = (int)m;  // list entries [0, pos) can matter to this quadrant
+  if (pos == 0) return;
+  const uint2 range = ranges[tile];
+  const uint32_t below = (1u << q) - 1u;
+  int nq = 0;
+
+  while (true) {
+    // ---- queue the next relevant entries (entries behind `pos` are done)
+    while (nq < 64 && pos > 0) {
+      const int e = pos - 1 - lane;
+      uint32_t slot = 0;
+      bool rel = false;
+      if (e >= 0) {
+        slot = point_list[range.x + e];
+        rel = ((qmask[slot] >> q) & 1u) != 0u;
+      }
+      const unsigned long long bal = __ballot(rel);
+      if (rel) {
+        const int at = nq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        sQe[at] = e;
+        sQs[at] = slot;
+      }
+      nq += __popcll(bal);
+      pos -= 64;
+    }
+    if (nq == 0) break;
+    const int take = nq < 64 ? nq : 64;
+    const bool act = lane < take;
+    const int e = act ? sQe[lane] : 0x7FFFFFFF;      // an idle lane is never `valid`
+    const uint32_t slot = act ? sQs[lane] : 0u;
+    const int rest = nq - take;                        // < 64: shift the remainder to the queue's front
+    const int me = lane < rest ? sQe[take + lane] : 0;
+    const uint32_t ms = lane < rest ? sQs[take + lane] : 0u;
+    if (lane < rest) { sQe[lane] = me; sQs[lane] = ms; }
+    nq = rest;
+    const int min_e = __shfl(e, take - 1, 64);         // frontmost record of the chunk
+
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, nn = a;
+    uint32_t row = 0;
+    if (act) {
+      const uint32_t g = gval[slot];
+      a = rec[4 * (size_t)g + 0];
+      b = rec[4 * (size_t)g + 1];
+      c = rec[4 * (size_t)g + 2];
+      if (MODE == MODE_SURFEL) nn = rec[4 * (size_t)g + 3];
+      row = cidx[slot] + (uint32_t)__builtin_popcount((unsigned)qmask[slot] & below);
+    }
+    const float zlo = a.w - b.w, zhi = a.w + b.w;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.f;
+
+    for (int pp = 0; pp < 64; ++pp) {
+      const float4 s0 = sPix[pp][0];
+      const int last_p = (int)__float_as_uint(s0.z);
+      if (last_p <= min_e) continue;                   // this pixel had stopped before the chunk's first record
+      const float4 s1 = sPix[pp][1], s2 = sPix[pp][2], s3 = sPix[pp][3];
+      const float T_p = s0.x, R_p = s0.y, coefT = s0.w;
+      const float dx = a.x - s2.w;
+      const float dy = a.y - s3.x;
+      const float p0 = -0.5f * (b.x * dx * dx);
+      const float pxy = b.y * dx;
+      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;   // the forward pass' op order
+      const float G = __expf(power);
+      const float raw = a.z * G;
+      const float alpha = fminf(ALPHA_MAX, raw);
+      const bool valid = (e < last_p) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      const float av = valid ? alpha : 0.f;
+      const float P_in = wave_incl_scan_mul(1.0f - av);     // product of (1 - alpha) over this and the records behind
+      const float P_ex = wave_shr1(P_in, 1.0f);
+      const float inv_P = __builtin_amdgcn_rcpf(P_in);
+      const float Tn = T_p * inv_P;                        // transmittance in front of this record
+      const float inv_one_m = P_ex * inv_P;                // 1 / (1 - alpha)
+      const float w = av * Tn;
+      // s = (upstream gradient) . (features of this record at this pixel)
+      float sdot = (c.x * s1.x + c.y * s1.y) + c.z * s1.z;
+      v[G_R] = fmaf(s1.x, w, v[G_R]);
+      v[G_G] = fmaf(s1.y, w, v[G_G]);
+      v[G_B] = fmaf(s1.z, w, v[G_B]);
+      if (MODE == MODE_SURFEL) {
+        sdot += (nn.x * s2.x + nn.y * s2.y) + nn.z * s2.z;
+        const float den = (nn.x * s3.y + nn.y * s3.z) + nn.z;
+        const bool hit = den < -DEN_EPS;
+        const float inv_den = __builtin_amdgcn_rcpf(den);
+        const float d0 = hit ? c.w * inv_den : a.w;
+        const float d = fminf(fmaxf(d0, zlo), zhi);
+        sdot = fmaf(d, s1.w, sdot);
+        const float gd = s1.w * w;
+        const bool lo = d0 < zlo, hi = d0 > zhi;
+        const bool mid = !lo && !hi;
+        v[G_ZLO] += lo ? gd : 0.f;
+        v[G_ZHI] += hi ? gd : 0.f;
+        const float gq = (mid && hit) ? gd * inv_den : 0.f;
+        v[G_Q] += gq;
+        v[G_PZ] += (mid && !hit) ? gd : 0.f;
+        const float gden = -gq * d0;
+        v[G_NX] += fmaf(gden, s3.y, s2.x * w);
+        v[G_NY] += fmaf(gden, s3.z, s2.y * w);
+        v[G_NZ] += s2.z * w + gden;
+      } else {
+        sdot = fmaf(a.w, s1.w, sdot);
+        v[G_PZ] = fmaf(s1.w, w, v[G_PZ]);
+      }
+      const float ws = w * sdot;
+      const float S_in = wave_incl_scan_add(ws);           // w s over this and the records behind (in the chunk)
+      const float R_l = R_p + wave_shr1(S_in, 0.f);        // blended behind this record, dotted with the gradient
+      // dL/dalpha = T s - (R - coefT) / (1 - alpha)
+      float dLda = fmaf(Tn, sdot, (coefT - R_l) * inv_one_m);
+      dLda = (valid && raw <= ALPHA_MAX) ? dLda : 0.f;     // no gradient through the active 0.99 clamp
+      v[G_OPAC] = fmaf(G, dLda, v[G_OPAC]);
+      const float dLp = raw * dLda;
+      const float qx = b.x * dx + b.y * dy, qy = b.y * dx + b.z * dy;
+      v[G_MX] -= dLp * qx;
+      v[G_MY] -= dLp * qy;
+      v[G_CONX] += 0.5f * qx * qx * dLp;
+      v[G_CONY] += qx * qy * dLp;
+      v[G_CONZ] += 0.5f * qy * qy * dLp;
+      if (lane == 63) {                                    // pixel state after the whole chunk
+        sPix[pp][0].x = Tn;
+        sPix[pp][0].y = R_p + S_in;
+      }
+    }
+    if (act) {
+      float4* dst = reinterpret_cast<float4*>(rows) + (size_t)row * 4;
+      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+      dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+      dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- balanced per-Gaussian row sums
 struct LiveOp {
   __host__ __device__ uint32_t operator()(const float& w) const { return w > 0.f ? 1u : 0u; }
@@ -649,9 +894,10 @@ struct BwdState {
 static BwdState carve_bwd(void* blob, int P, int64_t I) {
   Carver c(blob);
   BwdState b;
-  const size_t n = (size_t)(I > 0 ? I : 1), np = (size_t)(P > 0 ? P : 1);
+  // gradient rows: one per live (instance, 8x8 quadrant) pair in the Gaussian-per-lane kernel, i.e. at most 4 I
+  const size_t ni = (size_t)(I > 0 ? I : 1), n = 4 * ni, np = (size_t)(P > 0 ? P : 1);
   b.np_max = n / CH + np + 1;
-  b.cidx = c.take<uint32_t>(n + 2);
+  b.cidx = c.take<uint32_t>(ni + 2);
   b.cbeg = c.take<uint32_t>(np + 1);
   b.nch = c.take<uint32_t>(np + 1);
   b.pair_off = c.take<uint32_t>(np + 1);
@@ -659,7 +905,7 @@ static BwdState carve_bwd(void* blob, int P, int64_t I) {
   b.partials = c.take<float>(b.np_max * GRAD_ROW);
   b.tau_partials = c.take<float>((size_t)ceil_div((int)np, 256) * 6);
   size_t a = 0, d = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(n + 1));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(ni + 1));
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, d, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(np + 1));
   b.temp_bytes = align_up(a > d ? a : d) + 256;
   b.temp = c.take<char>(b.temp_bytes);
@@ -688,7 +934,8 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
                                     const float* dL_ddepth, const float* dL_dalpha,
                                     void* bwd_blob, float* dL_dmeans3D, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
-                                    float* dL_drotations, float* dL_dtau, void* stream) {
+                                    float* dL_drotations, float* dL_dtau, int footprint_class,
+                                    void* stream) {
   PINGS_ARG_CHECK(s != nullptr, "null settings");
   PINGS_ARG_CHECK(s->mode == PINGS_RASTER_SURFEL || s->mode == PINGS_RASTER_3DGS, "unknown mode");
   PINGS_ARG_CHECK(dL_dtau != nullptr, "null dL_dtau");
@@ -723,10 +970,21 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   ImageState im = carve_image(const_cast<void*>(image_blob), bp.W, bp.H);
   BwdState bw = carve_bwd(bwd_blob, P, I);
   const dim3 gridP(pings::ceil_div(P + 1, 256)), block(256);
+  // Blend backward kernel: Gaussian-per-lane wave scans when footprints are small (lanes of the pixel-per-lane kernel
+  // would idle: 2.25x faster on a street-like surfel scene), pixel-per-lane with two pixels per lane when they are
+  // large (chunks of the scan kernel would stay half empty and every instance would need four rows: 25 % faster on
+  // the Metric-1 cloud).  `footprint_class` comes from pings_raster_preprocess; PINGS_BLEND_BWD=pixel|scan overrides.
+  bool scan_mode = footprint_class != 2;
+  if (const char* e = getenv("PINGS_BLEND_BWD")) scan_mode = strcmp(e, "pixel") != 0;
 
   {
     pings::prof::Scope ps("live_scan", st);
-    if (I > 0) {
+    if (I > 0 && scan_mode) {
+      // one row per (instance, quadrant it blended in): inst_qmask has I+1 entries, the last one zero
+      hipcub::TransformInputIterator<uint32_t, PopOp, const uint8_t*> cnt(bs.inst_qmask, PopOp());
+      size_t tb = bw.temp_bytes;
+      PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(bw.temp, tb, cnt, bw.cidx, (int)(I + 1), st));
+    } else if (I > 0) {
       // inst_w has I+1 entries, the last one zero: cidx[I] = number of live instances
       hipcub::TransformInputIterator<uint32_t, LiveOp, const float*> flags(bs.inst_w, LiveOp());
       size_t tb = bw.temp_bytes;
@@ -742,9 +1000,20 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
     hipLaunchKernelGGL(pair_owner_kernel, gridP, block, 0, st, P, bw.pair_off, bw.pair_owner);
     PINGS_LAUNCH_CHECK();
   }
-  if (I > 0) {
+  if (I > 0 && scan_mode) {
     pings::prof::Scope ps("blend_bwd", st);
-    int ppl = blend_ppl_hint();
+    if (s->mode == PINGS_RASTER_SURFEL)
+      hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_SURFEL>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
+                         bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
+                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows);
+    else
+      hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_3DGS>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
+                         bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
+                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows);
+    PINGS_LAUNCH_CHECK();
+  } else if (I > 0) {
+    pings::prof::Scope ps("blend_bwd", st);
+    int ppl = footprint_class == 2 ? 2 : 1;
     if (const char* e = getenv("PINGS_BLEND_BWD_PPL")) ppl = atoi(e);
 #define PINGS_BLEND_BWD(M, L)                                                                            \
   hipLaunchKernelGGL((blend_bwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, bp, bs.ranges,    \

@@ -83,6 +83,7 @@ struct BinState {
   uint32_t *tile_key, *tile_key_sorted, *gval, *slot_val, *point_list;
   uint2* ranges;
   float* inst_w;       // [I+1] per-instance sum of blend weights (0 = instance never blended)
+  uint8_t* inst_qmask; // [I+1] 8x8 quadrants of the tile in which the instance blended something (bit q = qx + 2 qy)
   uint32_t* inst_cnt;  // [I]   per-instance pixel count with transmittance > 0.5 (3DGS)
   char* temp;
   size_t temp_bytes;
@@ -96,10 +97,6 @@ struct ImageState {
 };
 
 GeomState carve_geom(void* blob, int P, int num_tiles);
-// Pixels per lane the blend kernels of this thread's current view should use (1 or 2): chosen by
-// pings_raster_preprocess from the mean footprint (tiles per visible Gaussian), used by the render and
-// backward calls that follow on the same thread.  A stale value only costs speed.
-int& blend_ppl_hint();
 int occlusion_buckets(int num_tiles);
 BinState carve_binning(void* blob, int64_t I, int num_tiles);
 ImageState carve_image(void* blob, int W, int H);

@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "raster_common.hpp"
@@ -51,11 +52,6 @@ static size_t sort_temp_bytes(int64_t n) {
                                            (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 16);
   if (c > a) a = c;
   return align_up(a > b ? a : b) + 256;
-}
-
-int& blend_ppl_hint() {
-  static int hint = 2;  // process-wide: torch runs the backward on its own autograd thread
-  return hint;
 }
 
 // rank buckets per tile of the occlusion budget: ~2M counters in total, 32..256 per tile
@@ -97,6 +93,7 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.ranges = c.take<uint2>((size_t)num_tiles);
   b.inst_w = c.take<float>(n + 1);
   b.inst_cnt = c.take<uint32_t>(n);
+  b.inst_qmask = c.take<uint8_t>(n + 1);
   b.tile_key = c.take<uint32_t>(n);
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
@@ -568,7 +565,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_w,
-    uint32_t* __restrict__ inst_cnt) {
+    uint32_t* __restrict__ inst_cnt, uint8_t* __restrict__ inst_qmask, int want_qmask) {
   constexpr int NT = BLOCK / PPL;   // threads per workgroup
   constexpr int NWV = NT / 64;      // waves per workgroup
   constexpr int YS = 8;             // row distance of a lane's pixels
@@ -579,6 +576,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
   __shared__ uint32_t sSlot[BLOCK];
   __shared__ float sAcc[NWV][BLOCK];     // per-wave partial sums of blend weights
   __shared__ uint32_t sCnt[NWV][BLOCK];  // per-wave counts (3DGS n_touched)
+  __shared__ uint8_t sQb[NWV][BLOCK];    // per-wave bits: quadrants in which the record blended something
   __shared__ uint8_t sMask[BLOCK];       // quadrant mask of every staged record
   __shared__ uint8_t sList[NWV][BLOCK];  // per-wave compacted record indices (ascending)
 
@@ -647,6 +645,7 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
 #pragma unroll
         for (int wv = 0; wv < NWV; ++wv) {
           sAcc[wv][e] = 0.f;
+          if (PPL == 2) sQb[wv][e] = 0;
           if (MODE == MODE_3DGS) sCnt[wv][e] = 0u;
         }
       }
@@ -731,6 +730,16 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
         }
         const float s = wave_reduce_sum_dpp(wsum);
         if (lane == 63) sAcc[wave][j] = s;
+        if (PPL == 2 && want_qmask) {
+          // quadrants in which the record blended something, exactly (the Gaussian-per-lane backward kernel visits
+          // exactly these): a lane's pixel k lies in quadrant wave + 2 k.  With PPL 1 a wave IS a quadrant and the
+          // mask follows from sAcc; without `want_qmask` the pixel-per-lane backward kernel runs and needs none.
+          uint32_t qb = 0;
+#pragma unroll
+          for (int k = 0; k < PPL; ++k)
+            if (__ballot(contrib[k])) qb |= 1u << (wave + 2 * k);
+          if (lane == 63) sQb[wave][j] = (uint8_t)qb;
+        }
         if (MODE == MODE_3DGS) {
           const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
           if (lane == 63) sCnt[wave][j] = cn;
@@ -749,13 +758,16 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
       if (e < n) {
         float v = sAcc[0][e];
         uint32_t cn = (MODE == MODE_3DGS) ? sCnt[0][e] : 0u;
+        uint32_t qm = PPL == 1 ? (sAcc[0][e] != 0.f ? 1u : 0u) : (uint32_t)sQb[0][e];  // quadrants that blended
 #pragma unroll
         for (int wv = 1; wv < NWV; ++wv) {
           v += sAcc[wv][e];
+          qm |= PPL == 1 ? (sAcc[wv][e] != 0.f ? 1u << wv : 0u) : (uint32_t)sQb[wv][e];
           if (MODE == MODE_3DGS) cn += sCnt[wv][e];
         }
         if (v != 0.f) {  // untouched slots stay at their memset zero
           inst_w[sSlot[e]] = v;
+          inst_qmask[sSlot[e]] = (uint8_t)qm;
           if (MODE == MODE_3DGS) inst_cnt[sSlot[e]] = cn;
         }
       }
@@ -912,11 +924,12 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                                       const float* colors, const float* opacities,
                                       const float* scales, const float* rotations,
                                       void* geom_blob, int32_t* radii, int64_t* num_instances,
-                                      void* stream) {
+                                      int32_t* footprint_class, void* stream) {
   KParams kp;
   if (int e = make_params(s, P, kp)) return e;
-  PINGS_ARG_CHECK(num_instances != nullptr, "null num_instances");
+  PINGS_ARG_CHECK(num_instances != nullptr && footprint_class != nullptr, "null output");
   *num_instances = 0;
+  *footprint_class = 1;
   if (P == 0) return PINGS_OK;
   PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob && radii,
                   "null pointer");
@@ -988,7 +1001,7 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
   // Footprints of many tiles keep most lanes of a wave busy: two pixels per lane then amortise the per-record
   // work; small footprints leave lanes idle and one pixel per lane (four 8x8 waves with their own culled lists)
   // wins (measured: 52 tiles per Gaussian -> PPL 2 is 6 % faster, 5.6 tiles per Gaussian -> PPL 1 is 19 % faster).
-  blend_ppl_hint() = (stats[1] > 0 && stats[0] > 16ull * stats[1]) ? 2 : 1;
+  *footprint_class = (stats[1] > 0 && stats[0] > 16ull * stats[1]) ? 2 : 1;
   return PINGS_OK;
 }
 
@@ -996,7 +1009,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                                   void* geom_blob, void* binning_blob, void* image_blob,
                                   float* out_color, float* out_normal,
                                   float* out_depth, float* out_alpha, void* per_gaussian,
-                                  void* stream) {
+                                  int footprint_class, void* stream) {
   KParams kp;
   if (int e = make_params(s, P, kp)) return e;
   PINGS_ARG_CHECK(out_color && out_depth && out_alpha && image_blob && binning_blob, "null pointer");
@@ -1050,6 +1063,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                            (const uint32_t*)bs.tile_key_sorted, bs.ranges);
       PINGS_LAUNCH_CHECK();
       PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
+      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));
       if (s->mode == PINGS_RASTER_3DGS)
         PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st));
     }
@@ -1058,12 +1072,17 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   pings::prof::Scope ps_blend("blend_fwd", st);
   // pixels per lane: more pixels per lane amortise the per-Gaussian overhead but leave fewer waves;
   // 2 keeps >= 2 waves per tile (PINGS_BLEND_PPL overrides for experiments)
-  int ppl = blend_ppl_hint();
+  int ppl = footprint_class == 2 ? 2 : 1;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
+  // exact per-quadrant masks are needed iff the backward pass of this view will run the Gaussian-per-lane kernel
+  // (same predicate as pings_raster_backward: footprint class, PINGS_BLEND_BWD override); they only cost something
+  // in the 2-pixels-per-lane forward
+  int want_qmask = footprint_class != 2;
+  if (const char* e = getenv("PINGS_BLEND_BWD")) want_qmask = strcmp(e, "pixel") != 0;
 #define PINGS_BLEND_FWD(M, L)                                                                          \
   hipLaunchKernelGGL((blend_fwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, kp, bs.ranges,  \
                      bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,      \
-                     im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt)
+                     im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt, bs.inst_qmask, want_qmask)
   if (s->mode == PINGS_RASTER_SURFEL) {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
     else PINGS_BLEND_FWD(MODE_SURFEL, 2);

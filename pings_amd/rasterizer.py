@@ -137,15 +137,15 @@ def _declare(L):
     L.pings_raster_image_bytes.argtypes = [i32, i32]
     L.pings_raster_preprocess.restype = C.c_int
     L.pings_raster_preprocess.argtypes = [C.POINTER(_CSettings), i32, vp, vp, vp, vp, vp, vp, vp,
-                                          C.POINTER(C.c_int64), vp]
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]
     L.pings_raster_render.restype = C.c_int
     L.pings_raster_render.argtypes = [C.POINTER(_CSettings), i32, i64, vp, vp, vp, vp, vp, vp, vp,
-                                      vp, vp]
+                                      vp, i32, vp]
     L.pings_raster_backward_bytes.restype = C.c_size_t
     L.pings_raster_backward_bytes.argtypes = [i32, i64]
     if hasattr(L, "pings_raster_backward"):
         L.pings_raster_backward.restype = C.c_int
-        L.pings_raster_backward.argtypes = [C.POINTER(_CSettings), i32, i64] + [vp] * 25
+        L.pings_raster_backward.argtypes = [C.POINTER(_CSettings), i32, i64] + [vp] * 24 + [i32, vp]
     L.pings_raster_debug_lists.restype = C.c_int
     L.pings_raster_debug_lists.argtypes = [vp, i64, i32, i32, vp, vp, vp]
     L.pings_raster_debug_image.restype = C.c_int
@@ -173,7 +173,7 @@ def mark_visible(positions: torch.Tensor, prep: _Prepared) -> torch.Tensor:
 class _ForwardState:
     """Everything the backward pass needs (kept out of save_for_backward on purpose: the
     3DGS caller divides the returned depth in place, gaussian_renderer/__init__.py:430)."""
-    __slots__ = ("prep", "P", "I", "geom", "binning", "image", "means3D", "colors", "opacities",
+    __slots__ = ("prep", "P", "I", "fclass", "geom", "binning", "image", "means3D", "colors", "opacities",
                  "scales", "rotations", "color", "normal", "depth", "alpha")
 
 
@@ -188,9 +188,10 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     geom = torch.empty(L.pings_raster_geom_bytes(P, H, W), **u8)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
     n_inst = C.c_int64(0)
+    fclass = C.c_int32(1)
     st = L.pings_raster_preprocess(prep.ref(), P, _lib.ptr(means3D), _lib.ptr(colors),
                                    _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
-                                   _lib.ptr(geom), _lib.ptr(radii), C.byref(n_inst), stream)
+                                   _lib.ptr(geom), _lib.ptr(radii), C.byref(n_inst), C.byref(fclass), stream)
     _lib.check(st, "pings_raster_preprocess")
     I = int(n_inst.value)
     binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
@@ -206,10 +207,11 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
         per_g = torch.zeros(P, dtype=torch.int32, device=dev)
     st = L.pings_raster_render(prep.ref(), P, I, _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image),
                                _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth),
-                               _lib.ptr(alpha), _lib.ptr(per_g), stream)
+                               _lib.ptr(alpha), _lib.ptr(per_g), int(fclass.value), stream)
     _lib.check(st, "pings_raster_render")
     fs = _ForwardState()
     fs.prep, fs.P, fs.I = prep, P, I
+    fs.fclass = int(fclass.value)
     fs.geom, fs.binning, fs.image = geom, binning, image
     fs.means3D, fs.colors, fs.opacities, fs.scales, fs.rotations = means3D, colors, opacities, scales, rotations
     fs.color, fs.normal, fs.depth, fs.alpha = color, normal, depth, alpha
@@ -297,7 +299,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.ptr(fs.alpha), _lib.ptr(g_color), _lib.ptr(g_normal), _lib.ptr(g_depth),
             _lib.ptr(g_alpha), _lib.ptr(scratch), _lib.ptr(d_means3D), _lib.ptr(d_means2D),
             _lib.ptr(d_colors), _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_tau),
-            _lib.stream_ptr(dev))
+            fs.fclass, _lib.stream_ptr(dev))
         _lib.check(st, "pings_raster_backward")
         d_theta = d_tau[3:].clone() if ctx.has_pose[0] else None
         d_rho = d_tau[:3].clone() if ctx.has_pose[1] else None

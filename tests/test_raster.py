@@ -184,9 +184,13 @@ def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel"])
 @pytest.mark.parametrize("mode,front_only,seed", CASES + [("surfel", True, 31), ("3dgs", True, 32)])
-def test_gradients_match_fp64_oracle(mode, front_only, seed):
+def test_gradients_match_fp64_oracle(mode, front_only, seed, bwd_kernel, monkeypatch):
+    """Both blend-backward kernels (Gaussian-per-lane wave scans / pixel-per-lane reduce) against the fp64 oracle."""
     from pings_amd import rasterizer as hr
+
+    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel)
 
     sc = make_scene(400, 80, 64, seed=seed, surfel=(mode == "surfel"))
     dt = torch.float64
@@ -227,11 +231,13 @@ def test_gradients_match_fp64_oracle(mode, front_only, seed):
 
 
 @pytest.mark.gpu
-def test_backward_is_bitwise_deterministic():
+@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel"])
+def test_backward_is_bitwise_deterministic(bwd_kernel, monkeypatch):
     """No floating-point atomics anywhere: two backward passes give identical bits
     (the reference's CUDA op does not: mapper.py:1702-1704)."""
     from pings_amd import rasterizer as hr
 
+    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel)
     sc = make_scene(3000, 320, 200, seed=41)
     rast = hr.SurfelGaussianRasterizer(hip_settings(sc, "surfel", True))
     res = []
@@ -354,7 +360,16 @@ def test_full_size_properties_1m_gaussians_1080p():
         torch.autograd.backward([img, nrm, dep, alp], Gs)
         return [t.grad for t in leaves] + [th.grad, rh.grad]
 
+    import os
+    os.environ["PINGS_BLEND_BWD"] = "scan"      # large footprints default to the pixel kernel: exercise the other one too
+    try:
+        gs1, gs2 = grads(G1), grads(G1)
+    finally:
+        del os.environ["PINGS_BLEND_BWD"]
     ga, gb = grads(G1), grads(G2)
+    for a, b, c in zip(gs1, gs2, ga):
+        assert torch.equal(a, b)                                          # scan kernel: bitwise reproducible
+        assert (a.double() - c.double()).abs().max().item() <= 5e-4 * max(c.double().abs().max().item(), 1e-20)
     gc = grads([2.0 * a - 0.5 * b for a, b in zip(G1, G2)])
     for a, b, c in zip(ga, gb, gc):
         ref = 2.0 * a.double() - 0.5 * b.double()
