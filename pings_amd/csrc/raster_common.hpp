@@ -84,6 +84,8 @@ struct BinState {
   uint2* ranges;
   float* inst_w;       // [I+1] per-instance sum of blend weights (0 = instance never blended)
   uint8_t* inst_qmask; // [I+1] 8x8 quadrants of the tile in which the instance blended something (bit q = qx + 2 qy)
+  float* inst_wq;      // [I][4] per-(instance, quadrant) sums of the wave-per-quadrant forward kernel, folded into
+  uint32_t* inst_cntq; //        inst_w / inst_cnt / inst_qmask by combine_quadrants_kernel
   uint32_t* inst_cnt;  // [I]   per-instance pixel count with transmittance > 0.5 (3DGS)
   char* temp;
   size_t temp_bytes;

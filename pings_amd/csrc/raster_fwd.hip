@@ -94,6 +94,8 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.inst_w = c.take<float>(n + 1);
   b.inst_cnt = c.take<uint32_t>(n);
   b.inst_qmask = c.take<uint8_t>(n + 1);
+  b.inst_wq = c.take<float>(4 * n);
+  b.inst_cntq = c.take<uint32_t>(4 * n);
   b.tile_key = c.take<uint32_t>(n);
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
@@ -805,6 +807,184 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- forward, one independent wave per 8x8 quadrant
+// Footprint class 1 (footprints of a few tiles).  In the workgroup-per-tile kernel above the four waves of a tile
+// share the staging rounds, and as their culled lists differ in length (a wave visits ~37 % of the staged records
+// on a street-like scene) they idle at the round barriers and cannot stop before the slowest one.  Here every wave
+// walks the tile list by itself: 64 entries at a time it fetches slot -> Gaussian -> record (the next window is in
+// flight while the current one is blended), tests the footprint against ITS quadrant, compacts the survivors into
+// its own LDS slots and blends them; it stops as soon as its 64 pixels are done.  No barriers.  Per-instance sums
+// are written per quadrant (inst_wq / inst_cntq) and folded by combine_quadrants_kernel, so everything downstream
+// sees the same inst_w / inst_cnt / inst_qmask as from the workgroup kernel.  Pixel arithmetic is the same, op for op.
+template <int MODE>
+__global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
+    float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
+    uint32_t* __restrict__ inst_cntq) {
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
+  __shared__ uint32_t sSlot[64];
+  __shared__ int sE[64];
+  __shared__ float sW[64];
+  __shared__ uint32_t sCnt[64];
+
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
+  const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
+  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const float qx0 = (float)(tx * TILE + 8 * (q & 1)), qy0 = (float)(ty * TILE + 8 * (q >> 1));
+  const size_t HW = (size_t)p.W * p.H;
+  float rx = 0.f, ry = 0.f;
+  if (MODE == MODE_SURFEL) {
+    const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+    const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+    rx = (pixf_x - cxp) / p.fx;
+    ry = (pixf_y - cyp) / p.fy;
+  }
+  const uint2 range = ranges[tile];
+  const int todo = (int)(range.y - range.x);
+  const bool inside = pix_x < p.W && pix_y < p.H;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
+  uint32_t last = 0;
+  bool done = !inside;
+
+  // window being fetched: slot, Gaussian id, first two record quads of list entry base + lane
+  uint32_t f_slot = 0, f_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
+  bool f_ok = false;
+  auto fetch = [&](int base) {
+    const int e = base + lane;
+    f_ok = e < todo;
+    if (f_ok) {
+      f_slot = point_list[range.x + e];
+      f_g = gval[f_slot];
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+    }
+  };
+  if (todo > 0 && !__all(done)) fetch(0);
+
+  for (int base = 0; base < todo; base += 64) {
+    if (__all(done)) break;
+    const uint32_t slot = f_slot, g = f_g;
+    const float4 ra = f_a, rb = f_b;
+    const bool ok = f_ok;
+    if (base + 64 < todo) fetch(base + 64);               // in flight while this window is blended
+    bool rel = false;
+    if (ok) {
+      const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
+      rel = !footprint_misses_rect(ra.x, ra.y, rb.x, rb.y, rb.z, thr, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+    }
+    const unsigned long long bal = __ballot(rel);
+    const int n = __popcll(bal);
+    if (rel) {
+      const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      sA[at] = ra;
+      sB[at] = rb;
+      sC[at] = rec[4 * (size_t)g + 2];
+      if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+      sSlot[at] = slot;
+      sE[at] = base + lane;
+    }
+    sW[lane] = 0.f;
+    if (MODE == MODE_3DGS) sCnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+
+    for (int j = 0; j < n; ++j) {
+      const float4 a = sA[j], b = sB[j], c = sC[j];
+      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == MODE_SURFEL) nn = sD[j];
+      const float dx = a.x - pixf_x;
+      const float p0 = -0.5f * (b.x * dx * dx);
+      const float pxy = b.y * dx;
+      const float dy = a.y - pixf_y;
+      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      const float test_T = T * (1.0f - alpha);
+      const bool stop = valid && (test_T < T_EPS);
+      const bool contrib = valid && !stop;
+      done = done || stop;
+      if (__any(contrib)) {
+        const float w = contrib ? alpha * T : 0.f;
+        C0 = fmaf(c.x, w, C0);
+        C1 = fmaf(c.y, w, C1);
+        C2 = fmaf(c.z, w, C2);
+        uint32_t touched = 0;
+        if (MODE == MODE_SURFEL) {
+          const float den = (nn.x * rx + nn.y * ry) + nn.z;
+          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+          N0 = fmaf(nn.x, w, N0);
+          N1 = fmaf(nn.y, w, N1);
+          N2 = fmaf(nn.z, w, N2);
+          D = fmaf(d, w, D);
+        } else {
+          D = fmaf(a.w, w, D);
+          touched = (contrib && test_T > 0.5f) ? 1u : 0u;
+        }
+        T = contrib ? test_T : T;
+        last = contrib ? (uint32_t)(sE[j] + 1) : last;
+        const float s = wave_reduce_sum_dpp(w);
+        if (lane == 63) sW[j] = s;
+        if (MODE == MODE_3DGS) {
+          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
+          if (lane == 63) sCnt[j] = cn;
+        }
+      }
+      if (__all(done)) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      const float w = sW[lane];
+      if (w != 0.f) {  // untouched entries stay at their memset zero
+        inst_wq[4 * (size_t)sSlot[lane] + q] = w;
+        if (MODE == MODE_3DGS) inst_cntq[4 * (size_t)sSlot[lane] + q] = sCnt[lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (inside) {
+    const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+    const float A = 1.0f - T;
+    final_T[pix_id] = T;
+    n_contrib[pix_id] = last;
+    out_color[pix_id] = C0 + T * p.bg[0];
+    out_color[HW + pix_id] = C1 + T * p.bg[1];
+    out_color[2 * HW + pix_id] = C2 + T * p.bg[2];
+    out_alpha[pix_id] = A;
+    if (MODE == MODE_SURFEL) {
+      out_normal[pix_id] = N0;
+      out_normal[HW + pix_id] = N1;
+      out_normal[2 * HW + pix_id] = N2;
+      out_depth[pix_id] = D / fmaxf(A, DEPTH_ALPHA_EPS);
+    } else {
+      out_depth[pix_id] = D;
+    }
+  }
+}
+
+// inst_w[slot] = sum over the quadrants in fixed order, inst_cnt likewise, inst_qmask = quadrants that blended
+template <int MODE>
+__global__ __launch_bounds__(256) void combine_quadrants_kernel(int64_t I, const float4* __restrict__ wq,
+                                                                const uint4* __restrict__ cq, float* __restrict__ inst_w,
+                                                                uint32_t* __restrict__ inst_cnt,
+                                                                uint8_t* __restrict__ inst_qmask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  const float4 w = wq[i];
+  inst_w[i] = ((w.x + w.y) + w.z) + w.w;
+  inst_qmask[i] = (uint8_t)((w.x != 0.f ? 1u : 0u) | (w.y != 0.f ? 2u : 0u) | (w.z != 0.f ? 4u : 0u) | (w.w != 0.f ? 8u : 0u));
+  if (MODE == MODE_3DGS) {
+    const uint4 c = cq[i];
+    inst_cnt[i] = c.x + c.y + c.z + c.w;
+  }
+}
+
 __device__ inline uint32_t wave_reduce_sum_u32(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
@@ -1070,9 +1250,10 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   }
   {
   pings::prof::Scope ps_blend("blend_fwd", st);
-  // pixels per lane: more pixels per lane amortise the per-Gaussian overhead but leave fewer waves;
-  // 2 keeps >= 2 waves per tile (PINGS_BLEND_PPL overrides for experiments)
-  int ppl = footprint_class == 2 ? 2 : 1;
+  // pixels per lane: more pixels per lane amortise the per-Gaussian overhead but leave fewer waves; footprint class
+  // 2 (many tiles per Gaussian) -> 2, class 1 -> the wave-per-quadrant kernel (PINGS_BLEND_PPL = 1 | 2 forces the
+  // workgroup-per-tile kernel with that many pixels per lane)
+  int ppl = footprint_class == 2 ? 2 : 0;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
   // exact per-quadrant masks are needed iff the backward pass of this view will run the Gaussian-per-lane kernel
   // (same predicate as pings_raster_backward: footprint class, PINGS_BLEND_BWD override); they only cost something
@@ -1083,14 +1264,29 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   hipLaunchKernelGGL((blend_fwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, kp, bs.ranges,  \
                      bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,      \
                      im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt, bs.inst_qmask, want_qmask)
+#define PINGS_BLEND_FWD_WAVE(M)                                                                        \
+  do {                                                                                                 \
+    if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_wq, 0, 16 * (size_t)I, st));                     \
+    if (I > 0 && M == MODE_3DGS) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cntq, 0, 16 * (size_t)I, st)); \
+    hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(4 * num_tiles), dim3(64), 0, st, kp, bs.ranges, \
+                       bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
+                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq);                            \
+    if (I > 0)                                                                                         \
+      hipLaunchKernelGGL((combine_quadrants_kernel<M>), dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), \
+                         dim3(256), 0, st, I, reinterpret_cast<const float4*>(bs.inst_wq),              \
+                         reinterpret_cast<const uint4*>(bs.inst_cntq), bs.inst_w, bs.inst_cnt, bs.inst_qmask); \
+  } while (0)
   if (s->mode == PINGS_RASTER_SURFEL) {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
-    else PINGS_BLEND_FWD(MODE_SURFEL, 2);
+    else if (ppl == 2) PINGS_BLEND_FWD(MODE_SURFEL, 2);
+    else PINGS_BLEND_FWD_WAVE(MODE_SURFEL);
   } else {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_3DGS, 1);
-    else PINGS_BLEND_FWD(MODE_3DGS, 2);
+    else if (ppl == 2) PINGS_BLEND_FWD(MODE_3DGS, 2);
+    else PINGS_BLEND_FWD_WAVE(MODE_3DGS);
   }
 #undef PINGS_BLEND_FWD
+#undef PINGS_BLEND_FWD_WAVE
   PINGS_LAUNCH_CHECK();
   }
   if (P > 0) {
