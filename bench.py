@@ -77,7 +77,7 @@ def pmc_traffic(stage):
             return None, None, None
         data = json.load(open(files[-1]))
         for name, v in data.items():
-            if name.startswith(stage + "_kernel"):
+            if name.startswith(stage + "_"):
                 return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root)), v.get("valu_insts")
     except Exception:
         pass

@@ -1250,10 +1250,10 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   }
   {
   pings::prof::Scope ps_blend("blend_fwd", st);
-  // pixels per lane: more pixels per lane amortise the per-Gaussian overhead but leave fewer waves; footprint class
-  // 2 (many tiles per Gaussian) -> 2, class 1 -> the wave-per-quadrant kernel (PINGS_BLEND_PPL = 1 | 2 forces the
-  // workgroup-per-tile kernel with that many pixels per lane)
-  int ppl = footprint_class == 2 ? 2 : 0;
+  // the wave-per-quadrant kernel is the fastest forward on both footprint classes (Metric-1: 0.244 vs 0.265 ms for
+  // the workgroup-per-tile kernel with two pixels per lane; street-like scene: 0.86 vs 1.31 ms with one);
+  // PINGS_BLEND_PPL = 1 | 2 selects the workgroup-per-tile kernel with that many pixels per lane (A/B runs, tests)
+  int ppl = 0;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
   // exact per-quadrant masks are needed iff the backward pass of this view will run the Gaussian-per-lane kernel
   // (same predicate as pings_raster_backward: footprint class, PINGS_BLEND_BWD override); they only cost something

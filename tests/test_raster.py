@@ -151,11 +151,13 @@ def _check_list_prefixes(pl, rg, nc, o, W, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("occlusion", ["1", "0"])
+@pytest.mark.parametrize("occlusion,fwd_kernel", [("1", "0"), ("0", "0"), ("1", "1"), ("1", "2")])
 @pytest.mark.parametrize("mode,front_only,seed", CASES)
 @pytest.mark.parametrize("size", [(700, 112, 80), (1500, 200, 120), (40, 33, 17)])
-def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size, occlusion, monkeypatch):
+def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size, occlusion, fwd_kernel, monkeypatch):
+    """fwd_kernel: 0 = wave-per-quadrant (default), 1 / 2 = workgroup-per-tile with 1 / 2 pixels per lane."""
     monkeypatch.setenv("PINGS_RASTER_OCCLUSION", occlusion)
+    monkeypatch.setenv("PINGS_BLEND_PPL", fwd_kernel)
     P, W, H = size
     sc = make_scene(P, W, H, seed=seed, surfel=(mode == "surfel"))
     o, *_ = _oracle(sc, torch.float32, mode, front_only)
