@@ -259,7 +259,7 @@ __device__ inline void rot_active(const float* q, float vx, float vy, float vz, 
 }
 
 template <int IN_PAD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sdf_forward_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     pings_knn_map m, pings_sdf_decoder dec, const float* __restrict__ features,
     const float* __restrict__ points, const float* __restrict__ orientations,
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void upd_unpack_kernel(UpdArgs a) {
 }
 
 // ------------------------------------------------------------------ reset_local_map
+constexpr int kCountShards = 256;
 struct RstArgs {
   i64 Np;
   const float* pts;
@@ -303,8 +304,20 @@ __global__ __launch_bounds__(256) void rst_time_kernel(RstArgs a) {
     else t = abs(a.cur_ts - ts) < a.diff_ts_local;
     a.tflag[i] = t ? 1 : 0;
   }
+  // count of points inside the window: sharded (tens of thousands of waves adding to one word serialise)
   const unsigned long long b = __ballot(t);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.tcount, __popcll(b));
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.tcount + 1 + (blockIdx.x & (kCountShards - 1)), __popcll(b));
+}
+
+__global__ __launch_bounds__(256) void rst_total_kernel(int* __restrict__ tcount) {
+  __shared__ int red[256];
+  red[threadIdx.x] = tcount[1 + threadIdx.x];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tcount[0] = red[0];
 }
 
 __global__ __launch_bounds__(256) void rst_mask_kernel(RstArgs a) {
@@ -479,7 +492,7 @@ PINGS_API size_t pings_map_reset_local_scratch_bytes(int64_t num_points) {
   const size_t n = (size_t)(num_points > 0 ? num_points : 1);
   size_t scan = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
-  return up256(n) + up256(4 * n) * 2 + up256(scan) + 1024;
+  return up256(n) + up256(4 * n) * 2 + up256(scan) + 4096;
 }
 
 PINGS_API int pings_map_reset_local(int64_t num_points, const float* neural_points, const int32_t* point_ts_create,
@@ -511,17 +524,18 @@ PINGS_API int pings_map_reset_local(int64_t num_points, const float* neural_poin
   a.tflag = (uint8_t*)take(n);
   a.lflag = (int32_t*)take(4 * n);
   a.lpos = (int32_t*)take(4 * n);
-  a.tcount = (int*)take(sizeof(int));
+  a.tcount = (int*)take(sizeof(int) * (1 + kCountShards));  // [0] total, [1..] shards
   a.nlocal_dev = (i64*)take(sizeof(i64));
   void* temp = p + off;
   size_t tb = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
   a.local_mask = local_mask; a.sur_mask = sorrounding_mask; a.g2l = reinterpret_cast<i64*>(global2local); a.lidx = reinterpret_cast<i64*>(local_idx);
   pings::prof::Scope sc("map_reset_local", st);
-  PINGS_HIP_CHECK(hipMemsetAsync(a.tcount, 0, sizeof(int), st));
+  PINGS_HIP_CHECK(hipMemsetAsync(a.tcount, 0, sizeof(int) * (1 + kCountShards), st));
   if (a.temporal && num_points > 0) {
     PINGS_ARG_CHECK(!use_travel_dist || travel_dist, "travel-distance window without travel_dist");
     rst_time_kernel<<<blocks_for(num_points), 256, 0, st>>>(a);
+    rst_total_kernel<<<1, 256, 0, st>>>(a.tcount);
     PINGS_LAUNCH_CHECK();
   }
   rst_mask_kernel<<<blocks_for(num_points + 1), 256, 0, st>>>(a);
