@@ -94,7 +94,7 @@ __device__ inline float wave_reduce16(const float (&v)[16], int lane) {
 // PPL = pixels per lane (same lane -> pixel map as blend_fwd_kernel): the 16 gradient terms of a
 // lane's PPL pixels are summed in registers before the wave reduction, which is the expensive part.
 template <int MODE, int PPL>
-__global__ __launch_bounds__(BLOCK / PPL) void blend_bwd_kernel(
+__global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
     BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
