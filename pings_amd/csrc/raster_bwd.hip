@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void row_chunk_sum_kernel(int P, const uint32_
 
 // ---------------------------------------------------------------- per-Gaussian chain
 template <int MODE>
-__global__ __launch_bounds__(256) void gaussian_bwd_kernel(
+__global__ __launch_bounds__(256, 4) void gaussian_bwd_kernel(
     BParams p, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const uint32_t* __restrict__ gidx_sorted,
     const uint32_t* __restrict__ tiles_sorted, const uint32_t* __restrict__ pair_off,
