@@ -239,9 +239,11 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
                                 float* grad_x, int64_t* nn_counts, float* certainty,
-                                int64_t* idx_out, float* w_out, void* stream);
+                                int64_t* idx_out, float* w_out, float* sdf_std, void* stream);
 /* idx_out[B,nn_k] / w_out[B,nn_k] (optional): the neighbours (in the index space of `features`) and
- * their normalised inverse-distance weights, kept for pings_sdf_backward. */
+ * their normalised inverse-distance weights, kept for pings_sdf_backward.  sdf_std[B] (optional): spread of the
+ * per-neighbour predictions sqrt(sum_m w_m (s_m - sdf)^2), the tracker's validity filter
+ * (utils/tracker.py:303-313,408); 0 in weighted_first mode. */
 
 /* First-order backward of the fused query w.r.t. the feature table and the decoder
  * (the training path of Mapper.sdf_mapping, utils/mapper.py:822-970: loss(sdf).backward()).
@@ -406,5 +408,15 @@ PINGS_API size_t pings_depth2normal_backward_scratch_bytes(int H, int W);
 PINGS_API int pings_depth2normal_backward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
                                           float cx, float cy, float fx, float fy, float min_alpha,
                                           const float* dL_dnormal, void* scratch, float* dL_ddepth, void* stream);
+
+/* ------------------------------------------------------ tracker registration
+ * Replaces the Jacobian assembly of `implicit_reg` (utils/tracker.py:608-689): with J_i = [p_i x g_i, g_i] (rotation
+ * first, then translation),  N = sum_i w_i J_i^T J_i  (6x6)  and  g = -sum_i w_i r_i J_i  (6).
+ * points[n,3], sdf_grad[n,3], sdf_residual[n], weight[n] -> out[42] = N row-major (36) followed by g (6), fp32,
+ * accumulated in fp64 with a fixed-order two-stage reduction (bitwise reproducible).  The 6x6 solve, the LM damping and
+ * the exponential map stay on the host side of the ABI (a 6x6 fp64 inverse). */
+PINGS_API size_t pings_reg_normal_equations_scratch_bytes(void);
+PINGS_API int pings_reg_normal_equations(const float* points, const float* sdf_grad, const float* sdf_residual,
+                                         const float* weight, int64_t n, void* scratch, float* out, void* stream);
 
 #endif /* PINGS_HIP_H_ */

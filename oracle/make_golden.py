@@ -1,7 +1,7 @@
 """Generate the golden fixtures under tests/golden/ by running the REFERENCE's
 own Python on CPU (build container only; see oracle/ref_shim.py).
 
-    python -m oracle.make_golden [group ...]      # groups: ssim sdf spawn camera map
+    python -m oracle.make_golden [group ...]      # groups: ssim sdf spawn camera map tracker
 
 Fixtures are data only (inputs + the reference's outputs), small enough to be
 committed; the reference itself never travels to the GPU box.
@@ -366,7 +366,51 @@ def make_map(R):
         np.savez_compressed(OUT / f"map_{name}.npz", **out)
 
 
-GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map}
+# ---------------------------------------------------------------- G9 tracker registration step
+def make_tracker(R):
+    """G9: `implicit_reg` on synthetic residuals and `Tracker.query_source_points` (SDF head) on the maps of G1-G3."""
+    import types
+
+    import utils.tracker as T  # type: ignore
+
+    gen = torch.Generator().manual_seed(77)
+    out = {}
+    for tag, n, lam, cov in (("a", 5000, 0.0, True), ("b", 300, 1e-3, False)):
+        pts = (torch.rand(n, 3, generator=gen) - 0.5) * 30
+        grad = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1) * (1 + 0.1 * torch.randn(n, 1, generator=gen))
+        res = 0.05 * torch.randn(n, generator=gen)
+        w = torch.rand(n, 1, generator=gen)
+        Tm, cm, ev = T.implicit_reg(pts, grad, res, w, lm_lambda=lam, require_cov=cov, require_eigen=cov)
+        out.update({f"reg_{tag}_points": _np(pts), f"reg_{tag}_grad": _np(grad), f"reg_{tag}_res": _np(res),
+                    f"reg_{tag}_w": _np(w), f"reg_{tag}_lambda": np.float64(lam), f"reg_{tag}_T": _np(Tm)})
+        if cov:
+            out.update({f"reg_{tag}_cov": _np(cm), f"reg_{tag}_eig": _np(ev)})
+    for name in ("gs_f32", "pin_f8"):
+        kw = SDF_CASES[name]
+        cfg, npm = build_reference_map(R, kw, seed=len(name), after_pgo=False)
+        g2 = torch.Generator().manual_seed(99)
+        dec = R.Decoder(cfg, cfg.feature_dim, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+        with torch.no_grad():
+            for p_ in dec.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g2) * 0.3)
+        B = 700
+        base = npm.neural_points[torch.randint(0, npm.count(), (B,), generator=g2)]
+        x = base + torch.randn(B, 3, generator=g2) * 0.5 * cfg.voxel_size_m
+        x[:40] += 30.0
+        ref = np.load(OUT / f"sdf_{name}.npz")
+        assert np.array_equal(_np(x), ref["x"]), "G9 must reuse the queries of sdf_*.npz"
+        fake = types.SimpleNamespace(neural_points=npm, sdf_mlp=dec, config=cfg)
+        sdf, grad, _, _, _, mask, cert, std = T.Tracker.query_source_points(fake, x.clone(), 256, True, True, False,
+                                                                            False, query_locally=True,
+                                                                            mask_min_nn_count=5)
+        out.update({f"qsp_{name}_sdf": _np(sdf), f"qsp_{name}_grad": _np(grad), f"qsp_{name}_mask": _np(mask),
+                    f"qsp_{name}_cert": _np(cert), f"qsp_{name}_std": _np(std)})
+        print(f"tracker {name}: mask {int(mask.sum())}/{B}, |grad| mean {grad.norm(dim=1).mean():.3f}, std max {std.max():.4f}")
+    np.savez_compressed(OUT / "tracker_reg.npz", **out)
+
+
+GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map,
+          "tracker": make_tracker}
 
 
 def main(argv):

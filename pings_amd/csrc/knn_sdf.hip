@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,
     long long B, float* __restrict__ sdf_out, float* __restrict__ grad_out,
     long long* __restrict__ cnt_out, float* __restrict__ cert_out, long long* __restrict__ idx_out,
-    float* __restrict__ w_out) {
+    float* __restrict__ w_out, float* __restrict__ std_out) {
   __shared__ long long sIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ long long sGIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ float sD2[WAVES_PER_BLOCK][MAX_NNK];
@@ -422,6 +422,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       sdf_out[q] = S;
       if (grad_out) { grad_out[3 * q] = gx; grad_out[3 * q + 1] = gy; grad_out[3 * q + 2] = gz; }
       if (cnt_out) cnt_out[q] = count;
+      if (std_out) {
+        // spread of the per-neighbour predictions, sqrt(sum_m w_m (s_m - S)^2) (utils/tracker.py:303-308);
+        // stays 0 in weighted_first mode, as the reference's buffer does
+        float var = 0.f;
+        if (!dec.weighted_first)
+          for (int mm = 0; mm < nnk; ++mm) {
+            const float d = sS[wave][mm] - S;
+            var += sW[wave][mm] * (d * d);
+          }
+        std_out[q] = sqrtf(var);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -508,7 +519,7 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
                                 float* grad_x, int64_t* nn_counts, float* certainty,
-                                int64_t* idx_out, float* w_out, void* stream) {
+                                int64_t* idx_out, float* w_out, float* sdf_std, void* stream) {
   if (int e = check_map(m)) return e;
   PINGS_ARG_CHECK(dec && dec->W1 && dec->b1 && dec->W2 && dec->b2, "null decoder");
   PINGS_ARG_CHECK(dec->hidden > 0 && dec->hidden <= 64, "hidden must be in 1..64");
@@ -523,7 +534,7 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
 #define PINGS_SDF_LAUNCH(PAD)                                                                          \
   hipLaunchKernelGGL(sdf_forward_kernel<PAD>, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \
                      *dec, features, points, orientations, certainties, (int)after_pgo, queries,       \
-                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out)
+                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out, sdf_std)
   if (in_dim <= 12) PINGS_SDF_LAUNCH(12);
   else if (in_dim <= 36) PINGS_SDF_LAUNCH(36);
   else PINGS_SDF_LAUNCH(64);

@@ -1,0 +1,95 @@
+// Tracker registration step: normal equations of one point-to-implicit-model Gauss-Newton /
+// Levenberg-Marquardt iteration, utils/tracker.py:608-689 (`implicit_reg`, adapted there from LocNDF).
+//
+// With J_i = [p_i x g_i, g_i] (rotation first, then translation) the reference forms  N = J^T (w J)  and
+// g = -(J w)^T r  with two GEMMs over the n x 6 Jacobian after materialising the cross products, the concatenation
+// and the weighted copy (five n-sized temporaries).  Here one pass reads the 8 floats of a point and accumulates the
+// 21 distinct entries of N and the 6 of g in fp64 registers; wave shuffle + LDS reduce per workgroup, per-workgroup
+// partials in global memory, and a second tiny kernel sums them in fixed order: bitwise reproducible.  HBM bound:
+// 32 B per point.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTerms = 27;    // 21 upper-triangle entries of N, 6 of g
+constexpr int kBlocks = 512;
+
+__global__ __launch_bounds__(256) void reg_accumulate_kernel(const float* __restrict__ pts, const float* __restrict__ grad,
+                                                             const float* __restrict__ res, const float* __restrict__ wgt,
+                                                             long long n, double* __restrict__ partial) {
+  __shared__ double red[4][kTerms];
+  double acc[kTerms];
+#pragma unroll
+  for (int k = 0; k < kTerms; ++k) acc[k] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const float gx = grad[3 * i], gy = grad[3 * i + 1], gz = grad[3 * i + 2];
+    float J[6];
+    J[0] = py * gz - pz * gy;   // torch.linalg.cross(points, sdf_grad) in fp32, as the reference
+    J[1] = pz * gx - px * gz;
+    J[2] = px * gy - py * gx;
+    J[3] = gx; J[4] = gy; J[5] = gz;
+    const double w = (double)wgt[i], r = (double)res[i];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double wa = w * (double)J[a];
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[k++] += wa * (double)J[b];
+      acc[21 + a] -= wa * r;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kTerms; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kTerms)
+    partial[(size_t)blockIdx.x * kTerms + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void reg_finish_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ out) {
+  __shared__ double tot[kTerms];
+  const int k = threadIdx.x;
+  if (k < kTerms) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * kTerms + k];
+    tot[k] = v;
+  }
+  __syncthreads();
+  if (k == 0) {
+    int t = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) {
+        out[a * 6 + b] = (float)tot[t];
+        out[b * 6 + a] = (float)tot[t];
+        ++t;
+      }
+    for (int a = 0; a < 6; ++a) out[36 + a] = (float)tot[21 + a];
+  }
+}
+
+}  // namespace
+
+PINGS_API size_t pings_reg_normal_equations_scratch_bytes(void) { return sizeof(double) * kBlocks * kTerms; }
+
+PINGS_API int pings_reg_normal_equations(const float* points, const float* sdf_grad, const float* sdf_residual,
+                                         const float* weight, int64_t n, void* scratch, float* out, void* stream) {
+  PINGS_ARG_CHECK(n >= 0 && out && scratch, "bad argument");
+  PINGS_ARG_CHECK(n == 0 || (points && sdf_grad && sdf_residual && weight), "null input");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("reg_normal_equations", st);
+  int nb = (int)((n + 255) / 256);
+  nb = nb < 1 ? 1 : (nb > kBlocks ? kBlocks : nb);
+  reg_accumulate_kernel<<<nb, 256, 0, st>>>(points, sdf_grad, sdf_residual, weight, (long long)n,
+                                            reinterpret_cast<double*>(scratch));
+  PINGS_LAUNCH_CHECK();
+  reg_finish_kernel<<<1, 64, 0, st>>>(reinterpret_cast<const double*>(scratch), nb, out);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}

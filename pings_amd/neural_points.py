@@ -53,7 +53,7 @@ def _declare(L):
     L.pings_knn_compact_build.argtypes = [vp, C.c_int64, vp, C.c_size_t, vp]
     L.pings_sdf_forward.restype = C.c_int
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
-                                    C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+                                    C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_sdf_backward_scratch_bytes.restype = C.c_size_t
     L.pings_sdf_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
     L.pings_sdf_backward.restype = C.c_int
@@ -265,11 +265,12 @@ def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = Non
 
 def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certainty: bool = False,
               query_locally: bool = True, use_only_measured_points: bool = True,
-              use_only_valid_points: bool = False):
+              use_only_valid_points: bool = False, need_std: bool = False):
     """Fused inference query = `Mapper.sdf(x)` under no_grad (utils/mapper.py:2273-2289) and, with
     need_grad, the analytic gradient the tracker asks autograd for (utils/tracker.py:282-321).
 
-    Returns (sdf[B], grad[B,3] | None, nn_counts[B], certainty[B] | None).  `decoder` is the
+    Returns (sdf[B], grad[B,3] | None, nn_counts[B], certainty[B] | None) and, with need_std, a fifth value
+    sdf_std[B] (spread of the per-neighbour predictions, utils/tracker.py:303-313).  `decoder` is the
     reference's `Decoder` (model/decoder.py) with one hidden level, or any object with
     `layers[0].weight/.bias`, `lout.weight/.bias`, `sdf_scale`."""
     L = _L()
@@ -301,10 +302,14 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     grad = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_grad else None
     cnt = torch.empty(B, dtype=torch.int64, device=dev)
     cert = torch.empty(B, dtype=torch.float32, device=dev) if need_certainty else None
+    std = torch.empty(B, dtype=torch.float32, device=dev) if need_std else None
     st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(feats), _lib.ptr(pts), _lib.ptr(quat),
                              _lib.ptr(cert_tab), int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf),
-                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), None, None, _lib.stream_ptr(dev))
+                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), None, None, _lib.ptr(std),
+                             _lib.stream_ptr(dev))
     _lib.check(st, "pings_sdf_forward")
+    if need_std:
+        return sdf, grad, cnt, cert, std
     return sdf, grad, cnt, cert
 
 
@@ -334,7 +339,7 @@ class _SdfTrain(torch.autograd.Function):
         gx = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
         st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(f), _lib.ptr(pts), _lib.ptr(quat), None,
                                  int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf), _lib.ptr(gx), _lib.ptr(cnt),
-                                 None, _lib.ptr(idx), _lib.ptr(w), _lib.stream_ptr(dev))
+                                 None, _lib.ptr(idx), _lib.ptr(w), None, _lib.stream_ptr(dev))
         _lib.check(st, "pings_sdf_forward")
         ctx.save_for_backward(q, f, W1c, b1c, W2c, b2c, idx, w, pts, quat)
         ctx.gx = gx

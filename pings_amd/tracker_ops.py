@@ -1,0 +1,152 @@
+"""Tracker registration step on the HIP device.
+
+`query_source_points` — drop-in for `Tracker.query_source_points` (utils/tracker.py:212-351): SDF value, analytic SDF
+gradient, spread of the per-neighbour predictions, marching-cubes / registration mask and certainty of every source
+point come from ONE fused kernel launch per batch (`pings_sdf_forward`: hash-grid kNN + feature gather + decoder +
+IDW + d/dx), where the reference runs query_feature, the decoder, an autograd backward through all of it and a
+dozen element-wise kernels, 50-100 times per frame.  Colour / semantic queries, which only the photometric term
+needs, reuse the HIP-backed `query_feature` with the reference's own torch tail.
+
+`implicit_reg` — drop-in for the module-level function (utils/tracker.py:608-689): the 6x6 normal equations come from
+`pings_reg_normal_equations` (one pass, fp64 accumulation, fixed-order reduction); LM damping, the fp64 6x6 solve and
+the exponential map follow the reference line by line.
+
+`install(tracker_module)` rebinds both.  Host tensors raise: there is no CPU path (oracle/tracker_cpu.py is the
+CPU restatement used by the tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from . import neural_points as _np
+
+
+def _declare(L):
+    if getattr(L, "_trk_declared", False):
+        return
+    vp = C.c_void_p
+    L.pings_reg_normal_equations_scratch_bytes.restype = C.c_size_t
+    L.pings_reg_normal_equations_scratch_bytes.argtypes = []
+    L.pings_reg_normal_equations.restype = C.c_int
+    L.pings_reg_normal_equations.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+    L._trk_declared = True
+
+
+def normal_equations(points, sdf_grad, sdf_residual, weight):
+    """N[6,6] = J^T (w J), g[6] = -(J w)^T r with J = [points x sdf_grad, sdf_grad] (fp32 tensors on the device)."""
+    if not points.is_cuda:
+        raise _lib.PingsHipError("implicit_reg runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+    L = _lib.lib()
+    _declare(L)
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    p, g = f(points), f(sdf_grad)
+    r, w = f(sdf_residual).reshape(-1), f(weight).reshape(-1)
+    n = p.shape[0]
+    dev = p.device
+    out = torch.empty(42, dtype=torch.float32, device=dev)
+    scratch = torch.empty(L.pings_reg_normal_equations_scratch_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(L.pings_reg_normal_equations(_lib.ptr(p), _lib.ptr(g), _lib.ptr(r), _lib.ptr(w), n, _lib.ptr(scratch),
+                                            _lib.ptr(out), _lib.stream_ptr(dev)), "pings_reg_normal_equations")
+    return out[:36].view(6, 6), out[36:]
+
+
+def _skew(v):
+    S = torch.zeros(3, 3, device=v.device, dtype=v.dtype)
+    S[0, 1], S[0, 2] = -v[2], v[1]
+    S[1, 0], S[1, 2] = v[2], -v[0]
+    S[2, 0], S[2, 1] = -v[1], v[0]
+    return S
+
+
+def _expmap(axis_angle):
+    """utils/tracker.py:774-783."""
+    angle = axis_angle.norm()
+    axis = axis_angle / angle
+    eye = torch.eye(3, device=axis_angle.device, dtype=axis_angle.dtype)
+    S = _skew(axis)
+    return eye + S * torch.sin(angle) + (S @ S) * (1.0 - torch.cos(angle))
+
+
+def implicit_reg(points, sdf_grad, sdf_residual, weight, lm_lambda=0.0, require_cov=False, require_eigen=False):
+    """One LM step of point-to-implicit-model registration (utils/tracker.py:608-689): returns
+    (T_mat[4,4] fp64, cov_mat[6,6] | None, eigenvalues[3] | None)."""
+    N_mat, g_vec = normal_equations(points, sdf_grad, sdf_residual, weight)
+    N_mat = N_mat.clone()
+    if require_cov or require_eigen:
+        N_mat_raw = N_mat.clone()
+    N_mat += lm_lambda * torch.diag(torch.diag(N_mat))
+    t_vec = torch.linalg.inv(N_mat.to(dtype=torch.float64)) @ g_vec.to(dtype=torch.float64)
+    T_mat = torch.eye(4, device=points.device, dtype=torch.float64)
+    T_mat[:3, :3] = _expmap(t_vec[:3])
+    T_mat[:3, 3] = t_vec[3:]
+    eigenvalues = None
+    if require_eigen:
+        eigenvalues = torch.linalg.eigvals(N_mat_raw[3:, 3:]).real
+    cov_mat = None
+    if require_cov:
+        w = weight.reshape(-1)
+        mse = torch.mean(w * sdf_residual.reshape(-1) ** 2)
+        cov_mat = torch.linalg.inv(N_mat_raw) * mse
+    return T_mat, cov_mat, eigenvalues
+
+
+def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, query_color=False,
+                        query_color_grad=False, query_sem=False, query_mask=True, query_certainty=True,
+                        query_locally=True, mask_min_nn_count: int = 4):
+    """`Tracker.query_source_points` (utils/tracker.py:212-351): same arguments, same 8-tuple
+    (sdf_pred, sdf_grad, color_pred, color_grad, sem_pred, mc_mask, certainty, sdf_std)."""
+    if not coord.is_cuda:
+        raise _lib.PingsHipError("query_source_points runs on the HIP device only; there is no CPU fallback")
+    if query_sem:
+        raise NotImplementedError("semantic head: outside the PINGS hot path (no shipped config enables it)")
+    n = coord.shape[0]
+    dev = coord.device
+    iters = math.ceil(n / bs) if n else 0
+    sdf_pred = torch.zeros(n, device=dev) if query_sdf else None
+    sdf_std = torch.zeros(n, device=dev) if query_sdf else None
+    sdf_grad = torch.zeros(n, 3, device=dev) if query_sdf_grad else None
+    mc_mask = torch.zeros(n, device=dev, dtype=torch.bool) if query_mask else None
+    certainty = torch.zeros(n, device=dev) if query_certainty else None
+    channels = getattr(self.config, "color_channel", 3)
+    color_pred = torch.zeros(n, channels, device=dev) if query_color else None
+    color_grad = torch.zeros(n, channels, 3, device=dev) if query_color_grad else None
+    npm = self.neural_points
+    for k in range(iters):
+        head, tail = k * bs, min((k + 1) * bs, n)
+        x = coord[head:tail]
+        if query_sdf or query_mask or query_certainty:
+            s, g, cnt, cert, std = _np.sdf_fused(npm, self.sdf_mlp, x, need_grad=bool(query_sdf_grad),
+                                                 need_certainty=bool(query_certainty), query_locally=query_locally,
+                                                 use_only_valid_points=True, need_std=True)
+            if query_sdf:
+                sdf_pred[head:tail] = s
+                sdf_std[head:tail] = std
+            if query_sdf_grad:
+                sdf_grad[head:tail] = g
+            if query_mask:
+                mc_mask[head:tail] = cnt >= mask_min_nn_count
+            if query_certainty:
+                certainty[head:tail] = cert
+        if query_color:   # photometric term only: HIP-backed query_feature + the reference's torch tail (:322-331)
+            xc = x.detach().clone().requires_grad_(bool(query_color_grad))
+            _, color_feature, w_knn, _, _ = npm.query_feature(xc, accumulate_stability=False, query_locally=query_locally,
+                                                              query_color_feature=True, use_only_valid_points=True)
+            col = self.color_mlp.regress_color(color_feature)
+            if not self.config.weighted_first:
+                col = torch.sum(col * w_knn, dim=1)
+            if query_color_grad:
+                for i in range(channels):
+                    (gi,) = torch.autograd.grad(col[:, i].sum(), xc, retain_graph=True)
+                    color_grad[head:tail, i, :] = gi.detach()
+            color_pred[head:tail] = col.detach()
+    return sdf_pred, sdf_grad, color_pred, color_grad, None, mc_mask, certainty, sdf_std
+
+
+def install(tracker_module) -> None:
+    """`import utils.tracker as T; install(T)`: Tracker.query_source_points and implicit_reg -> HIP."""
+    tracker_module.Tracker.query_source_points = query_source_points
+    tracker_module.implicit_reg = implicit_reg

@@ -1,0 +1,89 @@
+"""Tracker registration step: `implicit_reg` and the SDF head of `Tracker.query_source_points`.
+The CPU oracle (oracle/tracker_cpu.py) is pinned by the reference's golden vectors (G9); the HIP path
+(pings_amd/tracker_ops.py -> csrc/tracker.hip, csrc/knn_sdf.hip) is checked against the same vectors."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import sdf_cpu, tracker_cpu
+from test_sdf import _Dec, _gpu_map, load, T
+
+TOL = 1e-4  # north_star: 1e-4 relative for floating point
+
+
+def _reg(golden_dir):
+    z = np.load(golden_dir / "tracker_reg.npz")
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_implicit_reg_matches_reference(golden_dir, tag):
+    st = _reg(golden_dir)
+    g = lambda k: T(st[f"reg_{tag}_{k}"])
+    cov = tag == "a"
+    Tm, cm, ev, _, _ = tracker_cpu.implicit_reg(g("points"), g("grad"), g("res"), g("w"), float(st[f"reg_{tag}_lambda"]),
+                                                require_cov=cov, require_eigen=cov)
+    assert rel_err(Tm, g("T")) <= 1e-9
+    if cov:
+        assert rel_err(cm, g("cov")) <= 1e-5 and rel_err(ev, g("eig")) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["gs_f32", "pin_f8"])
+def test_oracle_query_source_points_matches_reference(golden_dir, name):
+    st, ref = load(golden_dir, name), _reg(golden_dir)
+    npm, dec = sdf_cpu.NeuralPointMap(st), sdf_cpu.MLP.from_state(st)
+    s, g, mask, cert, std = tracker_cpu.query_source_points(npm, dec, T(st["x"]), mask_min_nn_count=5)
+    assert torch.equal(mask, T(ref[f"qsp_{name}_mask"]))
+    assert rel_err(s, T(ref[f"qsp_{name}_sdf"])) <= 1e-6 and rel_err(g, T(ref[f"qsp_{name}_grad"])) <= 1e-5
+    assert rel_err(cert, T(ref[f"qsp_{name}_cert"])) <= 1e-6
+    assert (std - T(ref[f"qsp_{name}_std"])).abs().max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_implicit_reg_matches_reference(golden_dir, tag):
+    from pings_amd import tracker_ops as TO
+
+    st = _reg(golden_dir)
+    g = lambda k: T(st[f"reg_{tag}_{k}"]).cuda()
+    cov = tag == "a"
+    Tm, cm, ev = TO.implicit_reg(g("points"), g("grad"), g("res"), g("w"), float(st[f"reg_{tag}_lambda"]),
+                                 require_cov=cov, require_eigen=cov)
+    assert rel_err(Tm, T(st[f"reg_{tag}_T"])) <= TOL
+    if cov:
+        assert rel_err(cm, T(st[f"reg_{tag}_cov"])) <= TOL and rel_err(ev, T(st[f"reg_{tag}_eig"])) <= TOL
+    # normal equations against fp64, and bitwise reproducible
+    N1, g1 = TO.normal_equations(g("points"), g("grad"), g("res"), g("w"))
+    N2, g2 = TO.normal_equations(g("points"), g("grad"), g("res"), g("w"))
+    assert torch.equal(N1, N2) and torch.equal(g1, g2)
+    c = lambda k: T(st[f"reg_{tag}_{k}"]).double()
+    _, _, _, N64, g64 = tracker_cpu.implicit_reg(c("points"), c("grad"), c("res"), c("w"))
+    assert rel_err(N1, N64) <= 1e-6 and rel_err(g1, g64) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gs_f32", "pin_f8"])
+def test_hip_query_source_points_matches_reference(golden_dir, name):
+    from pings_amd import tracker_ops as TO
+
+    st, ref = load(golden_dir, name), _reg(golden_dir)
+    fake = NS(neural_points=_gpu_map(st), sdf_mlp=_Dec(st), config=NS(weighted_first=bool(st["weighted_first"]), color_channel=3))
+    x = T(st["x"]).cuda()
+    sdf, grad, col, colg, sem, mask, cert, std = TO.query_source_points(fake, x, 256, True, True, False, False,
+                                                                       query_locally=True, mask_min_nn_count=5)
+    assert col is None and colg is None and sem is None
+    assert torch.equal(mask.cpu(), T(ref[f"qsp_{name}_mask"]))                 # exact (neighbour counts)
+    assert rel_err(sdf, T(ref[f"qsp_{name}_sdf"])) <= TOL
+    assert rel_err(grad, T(ref[f"qsp_{name}_grad"])) <= TOL
+    assert rel_err(cert, T(ref[f"qsp_{name}_cert"])) <= TOL
+    assert (std.cpu() - T(ref[f"qsp_{name}_std"])).abs().max() <= TOL * max(float(np.abs(ref[f"qsp_{name}_sdf"]).max()), 1e-3)
+
+
+def test_tracker_product_path_rejects_host_tensors():
+    from pings_amd import _lib, tracker_ops as TO
+
+    with pytest.raises(_lib.PingsHipError):
+        TO.implicit_reg(torch.rand(10, 3), torch.rand(10, 3), torch.rand(10), torch.rand(10, 1))
