@@ -256,6 +256,30 @@ def bench_sdf(dev, steps, warmup, n_points=1_000_000, batches=(16384, 131072)):
                         "hbm_sector_GBs_fwd": round(10400 * B / t_f / 1e9, 1),
                         "mean_nn_count": round(cnt.float().mean().item(), 2)}
         npm.local_geo_features = npm.geo_features
+    # one tracker registration iteration = query_source_points (sdf, d sdf/dx, std, mask, certainty:
+    # one fused kernel per batch) + implicit_reg (6x6 normal equations kernel + fp64 solve), 131072 source points
+    from types import SimpleNamespace as NS_
+    from pings_amd import tracker_ops as TO
+    B = 131072
+    x = sdf_queries(npm, B, dev)
+    fake = NS_(neural_points=npm, sdf_mlp=dec, config=NS_(weighted_first=False, color_channel=3))
+
+    def reg_step():
+        sdf, grad, _, _, _, mask, cert, std = TO.query_source_points(fake, x, B, True, True, False, False,
+                                                                    query_locally=True, mask_min_nn_count=4)
+        w = torch.ones(B, 1, device=dev) * mask[:, None]
+        return TO.implicit_reg(x, grad, sdf, w, lm_lambda=1e-4)
+
+    for _ in range(warmup):
+        reg_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        reg_step()
+    torch.cuda.synchronize()
+    t_r = (time.perf_counter() - t0) / steps
+    out["tracker_step"] = {"source_points": B, "ms_per_iteration": round(t_r * 1e3, 4),
+                           "Mpoints_s": round(B / t_r / 1e6, 2)}
     return out, npm, dec
 
 
