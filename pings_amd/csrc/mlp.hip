@@ -19,6 +19,8 @@
 // Partial Y^T / gX^T tiles of the NW waves are summed through LDS in fixed order; weight gradients are
 // kept in registers across all row tiles of the workgroup, written as per-workgroup partials and summed
 // by a second kernel in fixed order (bitwise reproducible, no atomics).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -106,8 +108,22 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __res
     __syncthreads();
     if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
     f32x16 acc = {0};
-    for (int s = 0; s < d.INP / 2; ++s)
-      acc = mfma(sW1[(wave * 32 + r) * d.ldw1 + 2 * s + h], sX[r * d.ldx + 2 * s + h], acc);
+    {
+      // the trip count is a kernel argument, which keeps hipcc from unrolling an MFMA loop: groups of four with a
+      // static inner loop let it issue the eight LDS operand reads of a group together, ahead of the four MFMAs
+      const float* pa = sW1 + (wave * 32 + r) * d.ldw1 + h;
+      const float* pb = sX + r * d.ldx + h;
+      const int half = d.INP / 2;
+      int s = 0;
+      for (; s + 4 <= half; s += 4) {
+        float a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a4[u] = pa[2 * (s + u)]; b4[u] = pb[2 * (s + u)]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma(a4[u], b4[u], acc);
+      }
+      for (; s < half; ++s) acc = mfma(pa[2 * s], pb[2 * s], acc);
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) acc[reg] = fmaxf(acc[reg] + bias1[reg], 0.f);
     f32x16 acc2 = {0};
@@ -124,6 +140,123 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __res
         float v = b2[o];
         for (int w = 0; w < NW; ++w) v += sY[(w * OUTP + o) * (TR + 1) + rr];
         y[(size_t)gr * d.OUT + o] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward, one independent wave per 32-row tile
+// For the GS decoders (HID = 128, IN <= 32, OUT <= 32: every shipped config).  A wave takes a 32-row tile from x to y
+// with no workgroup barrier, no LDS and no weight traffic after its prologue: both weight matrices live in its
+// registers as MFMA A-operand fragments (W1: 4 hidden blocks x 17 k-steps, W2: 4 x 16), the x tile is loaded straight
+// into the B-operand layout (the k order of the first product is free: lane half h takes inputs 16 h .. 16 h + 15,
+// sixteen contiguous floats of its row), the bias b1 rides along as one more k-step against a constant 1, and each
+// 32-unit block of the hidden layer goes accumulator -> ReLU -> B operand of the second product (accumulator-as-
+// operand chaining), which accumulates Y^T over the four blocks in ONE accumulator initialised with b2: no
+// cross-wave sum.  132 MFMAs per tile and wave; the next tile's x is in flight meanwhile.  Results are bitwise those
+// of the workgroup kernel's fma order up to the order of the hidden-block sum, i.e. within 1e-6.
+__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                              const float* __restrict__ W1, const float* __restrict__ b1,
+                                                              const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // ---- weight fragments
+  float w1f[4][17], w2f[4][16], b2f[16];
+  const bool vecw = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(W1) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(W2) & 15) == 0);
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    const int hid = hb * 32 + r;
+    if (vecw) {  // 16-byte loads: a lane's 16 inputs of a hidden unit, and its four runs of four hidden units of W2
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int k = 16 * h + 4 * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < IN) v = *reinterpret_cast<const float4*>(W1 + (size_t)hid * IN + k);
+        w1f[hb][4 * q4] = v.x; w1f[hb][4 * q4 + 1] = v.y; w1f[hb][4 * q4 + 2] = v.z; w1f[hb][4 * q4 + 3] = v.w;
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < OUT) u = *reinterpret_cast<const float4*>(W2 + (size_t)r * 128 + hb * 32 + 8 * q4 + 4 * h);
+        w2f[hb][4 * q4] = u.x; w2f[hb][4 * q4 + 1] = u.y; w2f[hb][4 * q4 + 2] = u.z; w2f[hb][4 * q4 + 3] = u.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int k = 16 * h + s;
+        w1f[hb][s] = k < IN ? W1[(size_t)hid * IN + k] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) w2f[hb][t] = r < OUT ? W2[(size_t)r * 128 + hb * 32 + rowmap(t, h)] : 0.f;
+    }
+    w1f[hb][16] = h == 0 ? b1[hid] : 0.f;            // k-step 16: (constant 1, zero) against (b1, 0)
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int o = rowmap(t, h);
+    b2f[t] = o < OUT ? b2[o] : 0.f;
+  }
+  const bool vec = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+  float xf[16], xn[16];
+  auto fetch = [&](long long t, float (&dst)[16]) {
+    const long long row = t * 32 + r;
+    const bool ok = row < N;
+    if (vec) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int k = 16 * h + 4 * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && k < IN) v = *reinterpret_cast<const float4*>(x + (size_t)row * IN + k);
+        dst[4 * q4 + 0] = v.x; dst[4 * q4 + 1] = v.y; dst[4 * q4 + 2] = v.z; dst[4 * q4 + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int k = 16 * h + s2;
+        dst[s2] = (ok && k < IN) ? x[(size_t)row * IN + k] : 0.f;
+      }
+    }
+  };
+  if (wave0 < ntiles) fetch(wave0, xn);
+  for (long long t = wave0; t < ntiles; t += nwaves) {
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) xf[s2] = xn[s2];
+    if (t + nwaves < ntiles) fetch(t + nwaves, xn);
+    const float one = h == 0 ? 1.f : 0.f;
+    f32x16 yacc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) yacc[q] = b2f[q];
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) acc = mfma(w1f[hb][s2], xf[s2], acc);
+      acc = mfma(w1f[hb][16], one, acc);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = fmaxf(acc[q], 0.f);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) yacc = mfma(w2f[hb][q], acc[q], yacc);
+    }
+    // Y^T[o = rowmap(q, h)][row = r]: four runs of four consecutive outputs per lane
+    const long long row = t * 32 + r;
+    if (row < N) {
+      float* dst = y + (size_t)row * OUT;
+      if (OUT % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int o = 8 * gq + 4 * h;
+          if (o < OUT)
+            *reinterpret_cast<float4*>(dst + o) = make_float4(yacc[4 * gq], yacc[4 * gq + 1], yacc[4 * gq + 2], yacc[4 * gq + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = rowmap(q, h);
+          if (o < OUT) dst[o] = yacc[q];
+        }
       }
     }
   }
@@ -223,8 +356,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
     }
     // H^T (hidden units of this wave) for the tile's rows
     f32x16 hT = {0};
-    for (int s = 0; s < d.INP / 2; ++s)
-      hT = mfma(sW1[(wave * 32 + r) * d.ldw1 + 2 * s + h], sX[r * d.ldx + 2 * s + h], hT);
+    {
+      const float* pa = sW1 + (wave * 32 + r) * d.ldw1 + h;
+      const float* pb = sX + r * d.ldx + h;
+      const int half = d.INP / 2;
+      int s = 0;
+      for (; s + 4 <= half; s += 4) {
+        float a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a4[u] = pa[2 * (s + u)]; b4[u] = pb[2 * (s + u)]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hT = mfma(a4[u], b4[u], hT);
+      }
+      for (; s < half; ++s) hT = mfma(pa[2 * s], pb[2 * s], hT);
+    }
     // gH^T = W2^T gY^T  (A = W2^T: row = hid on the lane, k = o)
     f32x16 gT = {0};
 #pragma unroll
@@ -375,7 +520,16 @@ PINGS_API int pings_mlp_forward(const float* x, int64_t N, int IN, int HID, int 
   hipStream_t st = pings::as_stream(stream);
   const Dims d = make_dims(N, IN, HID, OUT);
   const long long ntiles = (N + TR - 1) / TR;
-  const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
+  if (HID == 128 && IN <= 32 && getenv("PINGS_MLP_FWD_WG") == nullptr) {
+    // wave-per-tile kernel: 2 workgroups of 4 waves per CU (register-resident weights: 2 waves per SIMD)
+    pings::prof::Scope ps("mlp_fwd", st);
+    const long long want = (ntiles + 3) / 4;
+    const unsigned grid_w = (unsigned)(want < 512 ? want : 512);
+    hipLaunchKernelGGL(mlp_fwd_wave_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, IN, OUT, x, W1, b1, W2, b2, y);
+    PINGS_LAUNCH_CHECK();
+    return PINGS_OK;
+  }
+  const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);  // two resident workgroups per CU: weights are staged once each
   const size_t lds = fwd_lds_bytes(d);
   // prefetch registers per thread: ceil(32 * INP / threads), in three size classes
   const int need = (TR * d.INP + 64 * (HID / 32) - 1) / (64 * (HID / 32));
