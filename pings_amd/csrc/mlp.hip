@@ -458,6 +458,181 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
   if (wave == 0 && lane < d.OUT) pB2[lane] = aB2;
 }
 
+// ---------------------------------------------------------------- backward, one independent wave per 32-row tile
+// Same idea as mlp_fwd_wave_kernel, for HID = 128, IN <= 32: a wave takes a 32-row tile through all five products for
+// all four hidden blocks; nothing but the read-only weight images in LDS is shared, so the only barrier is the one
+// after staging them.  Per hidden block hb (k orders are free, lane half h takes k = 16 h .. 16 h + 15):
+//   A  pre^T  = W1_hb x^T (+ b1 as a 17th k-step)          A = register fragments of W1, B = x rows
+//   B  gH^T   = W2_hb^T gY^T, masked by pre > 0             A = W2 image in LDS,          B = gY rows
+//   C  gX^T  += W1_hb^T gH^T                                A = W1 image in LDS,          B = the gH^T accumulator
+//   D  gW2^T_hb += H^T gY,  gW1_hb += gH^T x  (sums over rows = lanes of the accumulators): H^T and gH^T make one
+//      trip through the wave's private LDS to become A operands, B = x / gY read column-wise from global memory;
+//      gb1 falls out of the transposed gH^T fragments, gb2 of the gY columns.
+// 324 MFMAs per tile.  Weight-gradient accumulators stay in registers across the wave's tiles (8 x 16 + 5 VGPRs),
+// are written as per-WAVE partials and summed by mlp_reduce_kernel in fixed order: bitwise reproducible.
+constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                              const float* __restrict__ gy, const float* __restrict__ W1,
+                                                              const float* __restrict__ b1, const float* __restrict__ W2,
+                                                              float* __restrict__ gx, float* __restrict__ partials,
+                                                              size_t per_block) {
+  __shared__ float sW1[128 * BW_LD];        // W1[hid][i], zero beyond IN
+  __shared__ float sW2[32 * 129];           // W2[o][hid], zero beyond OUT
+  __shared__ float sT[4][2][32 * BW_LD];    // per wave: H^T and gH^T as [hid_local][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 128 * 32; e += 256) {
+    const int j = e >> 5, i = e & 31;
+    sW1[j * BW_LD + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
+  }
+  for (int e = tid; e < 32 * 128; e += 256) {
+    const int o = e >> 7, j = e & 127;
+    sW2[o * 129 + j] = o < OUT ? W2[(size_t)o * 128 + j] : 0.f;
+  }
+  float b1f[4];  // bias k-step of product A: (b1, 0) against (1, 0)
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
+  __syncthreads();
+
+  f32x16 aW2T[4], aW1[4];
+  float aB1[4] = {0.f, 0.f, 0.f, 0.f}, aB2 = 0.f;
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { aW2T[hb][q] = 0.f; aW1[hb][q] = 0.f; }
+
+  float* myH = &sT[wave][0][0];
+  float* myG = &sT[wave][1][0];
+  const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const long long wave0 = (long long)blockIdx.x * 4 + wave;
+
+  float xn[16], gn[16];
+  auto fetch_rows = [&](long long t, float (&xd)[16], float (&gd)[16]) {
+    const long long row = t * 32 + r;
+    const bool ok = row < N;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int k = 16 * h + 4 * q4;
+      if (vecx) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && k < IN) v = *reinterpret_cast<const float4*>(x + (size_t)row * IN + k);
+        xd[4 * q4] = v.x; xd[4 * q4 + 1] = v.y; xd[4 * q4 + 2] = v.z; xd[4 * q4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = (ok && k + u < IN) ? x[(size_t)row * IN + k + u] : 0.f;
+      }
+      if (vecg) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && k < OUT) v = *reinterpret_cast<const float4*>(gy + (size_t)row * OUT + k);
+        gd[4 * q4] = v.x; gd[4 * q4 + 1] = v.y; gd[4 * q4 + 2] = v.z; gd[4 * q4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = (ok && k + u < OUT) ? gy[(size_t)row * OUT + k + u] : 0.f;
+      }
+    }
+  };
+  if (wave0 < ntiles) fetch_rows(wave0, xn, gn);
+  for (long long t = wave0; t < ntiles; t += nwaves) {
+    float xf[16], gyf[16], xcol[16], gycol[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) { xf[s2] = xn[s2]; gyf[s2] = gn[s2]; }
+    // column-wise views for the weight-gradient products: element [row = 16 h + s][column = r]
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const long long row = t * 32 + 16 * h + s2;
+      xcol[s2] = (row < N && r < IN) ? x[(size_t)row * IN + r] : 0.f;
+      gycol[s2] = (row < N && r < OUT) ? gy[(size_t)row * OUT + r] : 0.f;
+    }
+    if (t + nwaves < ntiles) fetch_rows(t + nwaves, xn, gn);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) aB2 += gycol[s2];
+    const float one = h == 0 ? 1.f : 0.f;
+    f32x16 gxacc = {0};
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      f32x16 pre = {0}, gH = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) pre = mfma(sW1[(hb * 32 + r) * BW_LD + 16 * h + s2], xf[s2], pre);
+      pre = mfma(b1f[hb], one, pre);
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) gH = mfma(sW2[(16 * h + s2) * 129 + hb * 32 + r], gyf[s2], gH);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        gH[q] = pre[q] > 0.f ? gH[q] : 0.f;
+        pre[q] = fmaxf(pre[q], 0.f);
+      }
+      if (gx) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gxacc = mfma(sW1[(hb * 32 + rowmap(q, h)) * BW_LD + r], gH[q], gxacc);
+      }
+      // transpose through the wave's private LDS: [hid_local][row]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        myH[rowmap(q, h) * BW_LD + r] = pre[q];
+        myG[rowmap(q, h) * BW_LD + r] = gH[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      float aH[16], aG[16];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        aH[s2] = myH[r * BW_LD + 16 * h + s2];
+        aG[s2] = myG[r * BW_LD + 16 * h + s2];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        aB1[hb] += aG[s2];
+        aW2T[hb] = mfma(aH[s2], gycol[s2], aW2T[hb]);
+        aW1[hb] = mfma(aG[s2], xcol[s2], aW1[hb]);
+      }
+    }
+    if (gx) {
+      const long long row = t * 32 + r;
+      if (row < N) {
+        float* dst = gx + (size_t)row * IN;
+        if (IN % 4 == 0 && ((reinterpret_cast<uintptr_t>(gx) & 15) == 0)) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int i = 8 * gq + 4 * h;
+            if (i < IN)
+              *reinterpret_cast<float4*>(dst + i) =
+                  make_float4(gxacc[4 * gq], gxacc[4 * gq + 1], gxacc[4 * gq + 2], gxacc[4 * gq + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int i = rowmap(q, h);
+            if (i < IN) dst[i] = gxacc[q];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- this wave's partial weight gradients
+  float* P = partials + ((size_t)blockIdx.x * 4 + wave) * per_block;
+  float* pW1 = P;
+  float* pW2 = pW1 + (size_t)128 * IN;
+  float* pB1 = pW2 + (size_t)OUT * 128;
+  float* pB2 = pB1 + 128;
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int hid = hb * 32 + rowmap(q, h);
+      if (r < OUT) pW2[(size_t)r * 128 + hid] = aW2T[hb][q];   // lane = o
+      if (r < IN) pW1[(size_t)hid * IN + r] = aW1[hb][q];      // lane = i
+    }
+    const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);      // the two row halves of hidden unit hb*32 + r
+    if (h == 0) pB1[hb * 32 + r] = v;
+  }
+  const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
+  if (h == 0 && r < OUT) pB2[r] = v2;
+}
+
 __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblocks, size_t per_block, int IN,
                                   int HID, int OUT, float* __restrict__ gW1, float* __restrict__ gb1,
                                   float* __restrict__ gW2, float* __restrict__ gb2) {
@@ -487,7 +662,7 @@ int check_dims(int64_t N, int IN, int HID, int OUT) {
   return PINGS_OK;
 }
 
-constexpr int MAX_BWD_BLOCKS = 512;
+constexpr int MAX_BWD_BLOCKS = 1024;  // per-workgroup partials (generic kernel) or per-wave partials (wave kernel)
 
 size_t fwd_lds_bytes(const Dims& d) {
   const int NW = d.HID / 32;
@@ -567,7 +742,20 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
   PINGS_ARG_CHECK(x && dL_dy, "null pointer");
   const Dims d = make_dims(N, IN, HID, OUT);
   const long long ntiles = (N + TR - 1) / TR;
-  const int grid = (int)(ntiles < MAX_BWD_BLOCKS ? ntiles : MAX_BWD_BLOCKS);
+  if (HID == 128 && IN <= 32 && getenv("PINGS_MLP_BWD_WG") == nullptr) {
+    pings::prof::Scope ps("mlp_bwd", st);
+    const long long want = (ntiles + 3) / 4;
+    const int grid_w = (int)(want < 256 ? want : 256);     // one workgroup (four independent waves) per CU
+    hipLaunchKernelGGL(mlp_bwd_wave_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, IN, OUT, x, dL_dy, W1, b1, W2,
+                       dL_dx, reinterpret_cast<float*>(scratch), per_block);
+    PINGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
+                       st, reinterpret_cast<const float*>(scratch), grid_w * 4, per_block, IN, HID, OUT, dL_dW1,
+                       dL_db1, dL_dW2, dL_db2);
+    PINGS_LAUNCH_CHECK();
+    return PINGS_OK;
+  }
+  const int grid = (int)(ntiles < 512 ? ntiles : 512);
   const size_t lds = bwd_lds_bytes(d);
   const int nthr = 64 * (HID / 32);
   const int need = (TR * d.INP + nthr - 1) / nthr;   // x prefetch registers per thread

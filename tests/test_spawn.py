@@ -30,7 +30,10 @@ class Dec(torch.nn.Module):
         self.to(device)
 
     def mlp_batch(self, x):
-        return self.lout(torch.relu(self.layers[0](x)))
+        pre = self.layers[0](x)
+        # rows with a hidden unit within fp32 rounding of the ReLU kink: the subgradient there is decided by rounding
+        self.kink_rows = (pre.detach().abs() < 1e-5).any(dim=1)
+        return self.lout(torch.relu(pre))
 
 
 def _run(st, device):
@@ -175,10 +178,21 @@ def test_spawn_hip_matches_oracle_random(opts):
             loss = loss + (res[kk] * w).sum()
         params = [p for n in DEC for p in decs[n].parameters()]
         grads = torch.autograd.grad(loss, [ge, ce] + params)
-        return res, grads, keys
+        kink = torch.stack([decs[n].kink_rows for n in DEC]).any(dim=0) if device == "cpu" else None
+        return res, grads, keys, kink
 
-    r_ref, g_ref, keys = run("cpu", torch.float64, ref_spawn)
-    r_hip, g_hip, _ = run("cuda", torch.float32, hip_spawn)
+    # neural points whose decoder pre-activations sit on a ReLU kink (|pre| < 1e-5: about one row in a few million
+    # products) have no gradient fp32 and fp64 can agree on -> move their features off the kink and draw again
+    rows = torch.arange(N) if no_mask else torch.nonzero(vis & valid).flatten()
+    for _ in range(4):
+        r_ref, g_ref, keys, kink = run("cpu", torch.float64, ref_spawn)
+        assert kink.numel() == rows.numel()
+        if not kink.any():
+            break
+        geo[rows[kink]] += 0.01
+        cfe[rows[kink]] += 0.01
+    assert not kink.any()
+    r_hip, g_hip, _, _ = run("cuda", torch.float32, hip_spawn)
     assert r_hip["local_view_gaussian_count"] == r_ref["local_view_gaussian_count"]
     assert torch.equal(r_hip["gaussian_free_mask"].cpu(), r_ref["gaussian_free_mask"])
     for kk in keys:
@@ -187,5 +201,5 @@ def test_spawn_hip_matches_oracle_random(opts):
     if opts.get("record_shifted"):
         assert r_hip["shifted_position"].shape == r_ref["shifted_position"].shape
         assert rel_err(r_hip["shifted_position"], r_ref["shifted_position"]) <= 1e-4
-    for a, b in zip(g_hip, g_ref):
-        assert rel_err(a, b) <= 1e-4
+    for i, (a, b) in enumerate(zip(g_hip, g_ref)):
+        assert rel_err(a, b) <= 1e-4, f"gradient {i} (0 geo features, 1 colour features, then decoder parameters)"
