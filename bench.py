@@ -323,6 +323,65 @@ def bench_decoder(dev, steps, warmup, n_points=125_000):
             "wall_ms_fwd_bwd_autograd": round(dt * 1e3, 4)}
 
 
+def bench_image_losses(dev, steps, warmup, W=1920, H=1080, with_cpu=True):
+    """the photometric loss block of the mapper (mapper.py:1197-1295) at 1080p, fused forward and
+    backward kernels against HBM: 61 B/pixel read forward, 61 B read + 44 B written backward."""
+    from pings_amd.image_losses import image_losses
+    from pings_amd import _lib
+
+    g = torch.Generator(device=dev).manual_seed(4)
+    r = lambda c: torch.rand(c, H, W, generator=g, device=dev)
+    rgb, gt, depth, alpha = r(3).requires_grad_(True), r(3), (1 + 9 * r(1)).requires_grad_(True), r(1).requires_grad_(True)
+    gt_depth = depth.detach() + 0.3 * (r(1) - 0.5)
+    n = torch.nn.functional.normalize(r(3) - 0.5, dim=0).requires_grad_(True)
+    m = torch.nn.functional.normalize(n.detach() + 0.3 * (r(3) - 0.5), dim=0).requires_grad_(True)
+    sky = r(1) < 0.2
+    opts = dict(depth_min=0.3, depth_max=20.0, depth_min_accu_alpha=0.4)
+
+    def step(fn, leaves, *a):
+        o = fn(*a, **opts)
+        o = o if isinstance(o, dict) else o._asdict()
+        tot = o["rgb_l1"] + 0.5 * o["depth_l1"] + 0.1 * o["normal_depth_consist"] + 0.1 * o["sky"]
+        return torch.autograd.grad(tot, leaves)
+
+    L = _lib.lib()
+    args = (rgb, gt, depth, gt_depth, alpha, n, m, sky)
+    leaves = [rgb, depth, alpha, n, m]
+    for _ in range(warmup):
+        step(image_losses, leaves, *args)
+    torch.cuda.synchronize()
+    L.pings_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(image_losses, leaves, *args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    L.pings_prof_enable(0)
+    buf = C.create_string_buffer(4096)
+    L.pings_prof_report(buf, len(buf))
+    prof = parse_prof(buf.value.decode())
+    t_f, t_b = prof["image_losses_fwd"][1] / steps * 1e-3, prof["image_losses_bwd"][1] / steps * 1e-3
+    px = W * H
+    out = {"width": W, "height": H, "fwd_ms": round(t_f * 1e3, 4), "bwd_ms": round(t_b * 1e3, 4),
+           "fwd_GBs": round(61 * px / t_f / 1e9, 1), "bwd_GBs": round(105 * px / t_b / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS,
+           "frac_of_hbm_peak_fwd_bwd": [round(61 * px / t_f / 1e9 / HBM_PEAK_GBS, 3), round(105 * px / t_b / 1e9 / HBM_PEAK_GBS, 3)],
+           "wall_ms_fwd_bwd_autograd": round(dt * 1e3, 4)}
+    if with_cpu:
+        from oracle.imgloss_cpu import image_losses as ref  # checker / CPU baseline leg only
+        cl = [t.detach().cpu().requires_grad_(True) for t in leaves]
+        ca = (cl[0], gt.cpu(), cl[1], gt_depth.cpu(), cl[2], cl[3], cl[4], sky.cpu())
+        step(ref, cl, *ca)
+        t0 = time.perf_counter()
+        k = 10
+        for _ in range(k):
+            step(ref, cl, *ca)
+        tc = (time.perf_counter() - t0) / k
+        out["cpu_baseline"] = {"value": round(px / tc / 1e6, 2), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/imgloss_cpu.py (reference torch op sequence), {k} fwd+bwd passes at {W}x{H}"}
+        out["Mpix_s_fwd_bwd_kernels"] = round(px / (t_f + t_b) / 1e6, 1)
+    return out
+
+
 def bench_map(dev, frames=6, n_scan=1_000_000, voxel=0.1, with_cpu=True):
     """per-frame map maintenance — voxel down-sampling + `update` (hash insert, appends) +
     `reset_local_map` + `assign_local_to_global` on a growing map (1M-point scans of a wavy street-sized sheet,
@@ -593,6 +652,7 @@ def main():
             torch.cuda.empty_cache()
         decoder = bench_decoder(dev, max(args.steps, 5), max(args.warmup, 2)) if not args.no_sdf else None
         map_maint = bench_map(dev, with_cpu=not args.no_cpu_baseline) if not args.no_sdf else None
+        img_losses = bench_image_losses(dev, max(args.steps, 5), max(args.warmup, 2), with_cpu=not args.no_cpu_baseline) if not args.no_sdf else None
         line = {
             "metric": "raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -606,7 +666,7 @@ def main():
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf, "decoder": decoder,
-            "map_maintenance": map_maint,
+            "map_maintenance": map_maint, "image_losses": img_losses,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -409,6 +409,38 @@ PINGS_API int pings_depth2normal_backward(const float* depth, const float* alpha
                                           float cx, float cy, float fx, float fy, float min_alpha,
                                           const float* dL_dnormal, void* scratch, float* dL_ddepth, void* stream);
 
+/* ------------------------------------------------------------ image-space losses
+ * Replaces the photometric loss block of `Mapper.joint_gsdf_mapping` (utils/mapper.py:1197-1295; helpers
+ * `l1_loss` / `sky_mask_loss`, gaussian_splatting/utils/loss_utils.py:17,178) — one fused pass per direction:
+ *   losses[0] = |rgb - gt_rgb|.mean() over rows [v_min, v_max)                                   (:1224-1239)
+ *   losses[1] = mean over (depth_min < gt_depth < depth_max) & (alpha > min_accu_alpha) of |gt - d|, or of
+ *               |1/gt - 1/d| when inverse_depth                                                    (:1251-1267)
+ *   losses[2] = mean over (|n| > 0) & (|m| > 0) of |m||n| - <n, m>, n = rendered normal, m = depth normal, both
+ *               zeroed at sky pixels first; norms detached; consist_mode 1 detaches n, 2 detaches m (:1213-1216,1273-1295)
+ *   losses[3] = alpha[sky].mean()                                                                  (:1198-1210)
+ * All un-weighted (the lambdas stay with the caller).  Planes are [C,H,W] fp32, sky_mask [H,W] uint8; depth/gt_depth,
+ * alpha, normal/depth_normal and sky_mask are optional (NULL); a mean over nothing is NaN as in torch.  `sums[8]`
+ * (fp64: sum, count per loss) is kept for the backward pass, which takes dL/dlosses[4] from device memory and writes
+ * whichever gradient planes are non-NULL. */
+typedef struct {
+  int H, W;
+  int v_min, v_max;          /* rows of the colour loss, v_max exclusive (python slice already resolved) */
+  float depth_min, depth_max, min_accu_alpha;
+  int inverse_depth;
+  int consist_mode;          /* 0 both sides learn, 1 gs_consist_normal_fixed, 2 gs_consist_depth_fixed */
+} pings_image_loss_params;
+PINGS_API size_t pings_image_losses_scratch_bytes(void);
+PINGS_API int pings_image_losses_forward(const pings_image_loss_params* p, const float* rgb, const float* gt_rgb,
+                                         const float* depth, const float* gt_depth, const float* alpha,
+                                         const float* normal, const float* depth_normal, const uint8_t* sky_mask,
+                                         void* scratch, double* sums, float* losses, void* stream);
+PINGS_API int pings_image_losses_backward(const pings_image_loss_params* p, const float* rgb, const float* gt_rgb,
+                                          const float* depth, const float* gt_depth, const float* alpha,
+                                          const float* normal, const float* depth_normal, const uint8_t* sky_mask,
+                                          const double* sums, const float* dL_dlosses, float* dL_drgb,
+                                          float* dL_ddepth, float* dL_dalpha, float* dL_dnormal,
+                                          float* dL_ddepth_normal, void* stream);
+
 /* ------------------------------------------------------ tracker registration
  * Replaces the Jacobian assembly of `implicit_reg` (utils/tracker.py:608-689): with J_i = [p_i x g_i, g_i] (rotation
  * first, then translation),  N = sum_i w_i J_i^T J_i  (6x6)  and  g = -sum_i w_i r_i J_i  (6).

@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import ref_shim
+from . import imgloss_cpu, ref_shim
 
 OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
 
@@ -409,8 +409,60 @@ def make_tracker(R):
     np.savez_compressed(OUT / "tracker_reg.npz", **out)
 
 
+# ---------------------------------------------------------------- G10 image-space loss block
+IMGLOSS_CASES = {
+    "sky_window": dict(H=40, W=56, sky=True, alpha=True, v=(3, 37), inverse=False, consist="both"),
+    "inverse_normal_fixed": dict(H=33, W=47, sky=False, alpha=True, v=(0, -1), inverse=True, consist="normal_fixed"),
+    "depth_fixed_no_alpha": dict(H=24, W=64, sky=False, alpha=False, v=(0, -1), inverse=False, consist="depth_fixed"),
+}
+IMGLOSS_W = (1.0, 0.7, 0.3, 0.2)  # weights of the scalar the gradients are taken of
+
+
+def make_imgloss(R):
+    """G10: the photometric loss block of utils/mapper.py:1197-1295.  The block is inline in a method that needs the
+    CUDA rasteriser, so it is evaluated here with the reference's own helpers (`l1_loss`, `sky_mask_loss`) and the
+    same torch expressions on the same tensors; values + autograd gradients of a weighted sum are stored."""
+    from gaussian_splatting.utils.loss_utils import l1_loss, sky_mask_loss  # type: ignore
+
+    gen = torch.Generator().manual_seed(2024)
+    for name, c in IMGLOSS_CASES.items():
+        t = imgloss_cpu.synthetic_inputs(c, gen)
+        leaf = {k: t[k].clone().requires_grad_(True) for k in ("rgb", "depth", "alpha", "normal", "dnormal") if t[k] is not None}
+        rgb, depth, alpha, rn, dn = leaf["rgb"], leaf["depth"], leaf.get("alpha"), leaf["normal"], leaf["dnormal"]
+        dmin, dmax, amin = 0.3, 20.0, 0.4
+        sky_loss = None
+        if t["sky"] is not None:
+            sky_loss = sky_mask_loss(t["sky"], alpha)
+            rn, dn = rn * ~t["sky"], dn * ~t["sky"]
+        v0, v1 = c["v"]
+        l1 = l1_loss(rgb[:, v0:v1, :], t["gt_rgb"][:, v0:v1, :])
+        ok = (t["gt_depth"] > dmin) & (t["gt_depth"] < dmax)
+        if alpha is not None:
+            ok = ok & (alpha.detach() > amin)
+        gd, rd = t["gt_depth"][ok], depth[ok]
+        dl = l1_loss(1.0 / gd, 1.0 / rd) if c["inverse"] else l1_loss(gd, rd)
+        rn_norm, dn_norm = rn.norm(2, dim=0).detach(), dn.norm(2, dim=0).detach()
+        okn = (rn_norm > 0) & (dn_norm > 0)
+        a, b = (rn.detach(), dn) if c["consist"] == "normal_fixed" else ((rn, dn.detach()) if c["consist"] == "depth_fixed" else (rn, dn))
+        cons = torch.masked_select(dn_norm * rn_norm - (a * b).sum(dim=0), okn).mean()
+        terms = [l1, dl, cons] + ([sky_loss] if sky_loss is not None else [])
+        total = sum(w * x for w, x in zip(IMGLOSS_W, terms))
+        names = list(leaf)
+        grads = torch.autograd.grad(total, [leaf[k] for k in names], allow_unused=True)
+        out = {f"in_{k}": _np(v) for k, v in t.items() if v is not None}
+        out.update(H=np.int64(c["H"]), W=np.int64(c["W"]), v=np.array(c["v"]), inverse=np.bool_(c["inverse"]),
+                   consist=np.array(c["consist"]), depth_min=np.float64(dmin), depth_max=np.float64(dmax),
+                   min_accu_alpha=np.float64(amin), rgb_l1=_np(l1), depth_l1=_np(dl), normal_depth_consist=_np(cons))
+        if sky_loss is not None:
+            out["sky"] = _np(sky_loss)
+        for k, g in zip(names, grads):
+            out[f"grad_{k}"] = _np(g if g is not None else torch.zeros_like(leaf[k]))
+        np.savez_compressed(OUT / f"imgloss_{name}.npz", **out)
+        print(f"imgloss_{name}: l1 {l1.item():.4f} depth {dl.item():.4f} consist {cons.item():.4f} valid depth {int(ok.sum())} normals {int(okn.sum())}")
+
+
 GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map,
-          "tracker": make_tracker}
+          "tracker": make_tracker, "imgloss": make_imgloss}
 
 
 def main(argv):

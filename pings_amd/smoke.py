@@ -133,6 +133,23 @@ def _map(dev):
           int(mh.local_neural_points.shape[0]), "local")
 
 
+def _image_losses(dev):
+    """The photometric loss block on a small frame against the fp64 CPU oracle."""
+    from oracle import imgloss_cpu as IC
+    from pings_amd.image_losses import image_losses
+
+    t = IC.synthetic_inputs(dict(H=60, W=80, sky=True, alpha=True), torch.Generator().manual_seed(3))
+    opts = dict(depth_min=0.3, depth_max=20.0, depth_min_accu_alpha=0.4)
+    ref = IC.image_losses(t["rgb"].double(), t["gt_rgb"].double(), t["depth"].double(), t["gt_depth"].double(),
+                          t["alpha"].double(), t["normal"].double(), t["dnormal"].double(), t["sky"], **opts)
+    c = lambda k: t[k].to(dev)
+    out = image_losses(c("rgb"), c("gt_rgb"), c("depth"), c("gt_depth"), c("alpha"), c("normal"), c("dnormal"), c("sky"),
+                       **opts)._asdict()
+    for k, v in ref.items():
+        assert abs(float(out[k]) - float(v)) <= 1e-5 * abs(float(v)), k
+    print("smoke: image losses ok", {k: round(float(out[k]), 5) for k in ref})
+
+
 def run() -> None:
     dev = torch.device("cuda:0")
     _ssim(dev)
@@ -140,3 +157,4 @@ def run() -> None:
     _sdf(dev)
     _mlp(dev)
     _map(dev)
+    _image_losses(dev)
