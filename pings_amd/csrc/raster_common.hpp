@@ -30,6 +30,11 @@ constexpr float T_EPS = 1e-4f;
 constexpr float DEPTH_ALPHA_EPS = 1e-10f;
 constexpr float DEN_EPS = 1e-6f;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
+constexpr int DS_NB = 1 << 18;        // depth-sort buckets
+constexpr uint32_t DS_LIMIT = 4096u;  // bucket population beyond which the library sort takes over
+constexpr int DS_SHARDS = 64;  // single-address atomics serialise at ~12 ns each on this part: spread them
+// header words: [0, 64) max key shards, [64, 128) max ~key shards, 128 kmin, 129 shift, 130 overflow flag
+constexpr int DS_KMIN = 2 * DS_SHARDS, DS_SHIFT = DS_KMIN + 1, DS_FLAG = DS_KMIN + 2, DS_HEAD = DS_KMIN + 8;
 // occlusion culling of instances (see occl_budget_kernel)
 constexpr float OCC_THR = 9.5f;     // > -ln(T_EPS) = 9.21: transmittance bound that guarantees every pixel has stopped
 constexpr float OCC_FIX = 4096.f;   // fixed-point scale of the budget (integer atomics: order independent)
@@ -70,6 +75,10 @@ struct GeomState {
   uint32_t* occ_bucket;                     // [occ_nb][num_tiles] fixed-point opacity budget per (rank bucket, tile)
   uint16_t* occ_bsat;                       // [num_tiles] last rank bucket a tile still needs (0xFFFF = all)
   uint32_t* nvalid;                         // [1] Gaussians that survived culling (= ranks with a real depth key)
+  uint32_t* ds_head;                        // depth sort: header (key range shards, range, overflow flag), then
+  uint32_t *ds_cnt, *ds_fill, *ds_off;      //   [DS_NB + blocks] bucket / per-block culled counts, [DS_NB] fill cursors,
+  size_t ds_words;                          //   [DS_NB + blocks + 1] their exclusive scan; ds_words = memset extent
+  uint32_t* ds_idx;                         //   [P] Gaussian ids in bucket order (keys go to depth_key_sorted)
   unsigned long long* stats;                // [2] pairs before occlusion culling, visible Gaussians
   int occ_nb;
   char* temp;

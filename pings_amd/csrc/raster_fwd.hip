@@ -21,6 +21,7 @@
 // (this TU is compiled with -ffp-contract=off; IEEE divide / sqrt), so radii, tile
 // rectangles and the sort order match the fp32 oracle bit for bit.
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 #include <cstdlib>
 #include <cstring>
@@ -46,7 +47,8 @@ static size_t sort_temp_bytes(int64_t n) {
   size_t a = 0, b = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                      (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                         (int)std::max<int64_t>(n, DS_NB + n / 256 + 2));
   size_t c = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (uint16_t*)nullptr, (uint16_t*)nullptr,
                                            (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 16);
@@ -78,6 +80,13 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.occ_bucket = c.take<uint32_t>(nt * (size_t)g.occ_nb);
   g.occ_bsat = c.take<uint16_t>(nt);
   g.nvalid = c.take<uint32_t>(1);
+  const size_t nblk = (n + 255) / 256;                  // workgroups of the per-Gaussian kernels
+  g.ds_words = DS_HEAD + 2 * (size_t)DS_NB + nblk;      // header, counts (+ per-block culled), fill cursors: one memset
+  g.ds_head = c.take<uint32_t>(g.ds_words);
+  g.ds_cnt = g.ds_head ? g.ds_head + DS_HEAD : nullptr;
+  g.ds_fill = g.ds_head ? g.ds_cnt + DS_NB + nblk : nullptr;
+  g.ds_off = c.take<uint32_t>((size_t)DS_NB + nblk + 1);
+  g.ds_idx = c.take<uint32_t>(n);
   g.stats = c.take<unsigned long long>(2 * 256);  // sharded {pairs before culling, visible Gaussians}
   g.temp_bytes = sort_temp_bytes((int64_t)n);
   g.temp = c.take<char>(g.temp_bytes);
@@ -352,6 +361,131 @@ __device__ inline float tile_min_alpha(float mx, float my, float o, float cx, fl
   m = fminf(m, edge_min_q(cz, cy, cx, hy, lx, hx));
   if (!(m > 1e-6f)) return 0.f;
   return a;
+}
+
+// ---------------------------------------------------------------- depth order of the preprocessed Gaussians
+// A library radix / merge sort of P = 1M (key, index) pairs costs 20 launches and 150 us, more than the preprocess
+// pass itself, although only the ~30 % that survive culling need an order.  Here: the key range of the survivors
+// (two atomics per wave) -> 2^18 equal-width buckets of the KEY BITS (monotone in depth; positive floats order as
+// integers) -> histogram -> exclusive scan -> scatter in arrival order -> every element ranks itself among its
+// bucket mates by (key, index), which is the stable order of a full sort, whatever the arrival order was: the result
+// is bit-identical to the library sort.  Culled Gaussians fill ranks [nvalid, P) in any order (they own no tiles; the
+// per-rank kernels only need a permutation).  Buckets average a handful of elements; one beyond DS_LIMIT (many
+// Gaussians at exactly one depth) raises a flag the host reads at its one synchronisation point and the library
+// sort redoes the frame.
+struct DsRange { uint32_t kmin, shift; };
+
+__device__ inline DsRange ds_range(const uint32_t* __restrict__ head) { return DsRange{head[DS_KMIN], head[DS_SHIFT]}; }
+
+__global__ __launch_bounds__(256) void ds_minmax_kernel(int P, const uint32_t* __restrict__ key, uint32_t* __restrict__ head) {
+  __shared__ uint32_t sm[8];
+  uint32_t mx = 0u, mn = 0u;  // max key, max ~key over valid entries
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < P; g += gridDim.x * 256) {
+    const uint32_t k = key[g];
+    if (k != CULLED_KEY) { mx = max(mx, k); mn = max(mn, ~k); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    mn = max(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[wave] = mx; sm[4 + wave] = mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    mn = max(max(sm[4], sm[5]), max(sm[6], sm[7]));
+    if (mx | mn) {
+      atomicMax(&head[blockIdx.x % DS_SHARDS], mx);
+      atomicMax(&head[DS_SHARDS + blockIdx.x % DS_SHARDS], mn);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void ds_range_kernel(uint32_t* __restrict__ head) {
+  uint32_t mx = head[threadIdx.x], mn = head[DS_SHARDS + threadIdx.x];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    mn = max(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t kmin = ~mn;
+    uint32_t shift = 0u;
+    if (mx > kmin)
+      while (((mx - kmin) >> shift) >= (uint32_t)DS_NB) ++shift;
+    head[DS_KMIN] = kmin;
+    head[DS_SHIFT] = shift;
+  }
+}
+
+// bucket histogram of the survivors; culled Gaussians are counted per workgroup (cnt[DS_NB + block]) so that the one
+// exclusive scan over [bucket counts | per-block culled counts] also yields each block's first culled rank
+__global__ __launch_bounds__(256) void ds_hist_kernel(int P, const uint32_t* __restrict__ key, const uint32_t* __restrict__ head,
+                                                       uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t sc[4];
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t k = g < P ? key[g] : 0u;
+  const bool culled = g < P && k == CULLED_KEY;
+  if (g < P && !culled) {
+    const DsRange r = ds_range(head);
+    atomicAdd(&cnt[(k - r.kmin) >> r.shift], 1u);
+  }
+  const unsigned long long bal = __ballot(culled);
+  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[DS_NB + blockIdx.x] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+}
+
+__global__ __launch_bounds__(256) void ds_scatter_kernel(int P, const uint32_t* __restrict__ key, const uint32_t* __restrict__ head,
+                                                          const uint32_t* __restrict__ off, uint32_t* __restrict__ fill,
+                                                          uint32_t* __restrict__ tmp_key, uint32_t* __restrict__ tmp_idx,
+                                                          uint32_t* __restrict__ gidx_sorted) {
+  __shared__ uint32_t sc[4];
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t k = g < P ? key[g] : 0u;
+  const bool culled = g < P && k == CULLED_KEY;
+  if (g < P && !culled) {
+    const DsRange r = ds_range(head);
+    const uint32_t b = (k - r.kmin) >> r.shift;
+    const uint32_t slot = off[b] + atomicAdd(&fill[b], 1u);
+    tmp_key[slot] = k;
+    tmp_idx[slot] = (uint32_t)g;
+  }
+  // culled Gaussians take ranks [nvalid, P) in index order
+  const unsigned long long bal = __ballot(culled);
+  if (lane == 0) sc[wave] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (culled) {
+    uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) before += sc[w];
+    gidx_sorted[off[DS_NB + blockIdx.x] + before] = (uint32_t)g;
+  }
+}
+
+__global__ __launch_bounds__(256) void ds_rank_kernel(const uint32_t* __restrict__ tmp_key, const uint32_t* __restrict__ tmp_idx,
+                                                       uint32_t* __restrict__ head, const uint32_t* __restrict__ off,
+                                                       uint32_t* __restrict__ gidx_sorted, uint32_t* __restrict__ nvalid) {
+  const uint32_t n = off[DS_NB];
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s == 0u) *nvalid = n;
+  if (s >= n) return;
+  const uint32_t k = tmp_key[s], id = tmp_idx[s];
+  const DsRange r = ds_range(head);
+  const uint32_t b = (k - r.kmin) >> r.shift;
+  const uint32_t lo = off[b], hi = off[b + 1];
+  if (hi - lo > DS_LIMIT) {  // degenerate depth distribution: keep a valid permutation, let the host redo the sort
+    gidx_sorted[s] = id;
+    if (s == lo) head[DS_FLAG] = 1u;
+    return;
+  }
+  uint32_t rank = 0u;
+  for (uint32_t t = lo; t < hi; ++t) {
+    const uint32_t kt = tmp_key[t], it = tmp_idx[t];
+    rank += (kt < k || (kt == k && it < id)) ? 1u : 0u;
+  }
+  gidx_sorted[lo + rank] = id;
 }
 
 // ranks [0, nvalid) hold the Gaussians with a real depth key (culled ones sort last): first culled rank,
@@ -1127,54 +1261,81 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                          opacities, scales, rotations, gs.rec, gs.rect, gs.depth_key, gs.gidx, radii);
     PINGS_LAUNCH_CHECK();
   }
-  size_t tb = gs.temp_bytes;
-  {
-    pings::prof::Scope ps("depth_sort", st);
-    PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
-                                                       gs.gidx, gs.gidx_sorted, P, 0, 32, st));
-  }
-  // PINGS_RASTER_OCCLUSION=0 keeps every (Gaussian, tile) instance (A/B runs, list-parity tests)
+  // PINGS_RASTER_OCCLUSION=0 keeps every (Gaussian, tile) instance (A/B runs, list-parity tests);
+  // PINGS_DEPTH_SORT=library forces the rocPRIM sort (A/B runs, parity tests of the bucket sort)
   bool occlusion = true;
   if (const char* e = getenv("PINGS_RASTER_OCCLUSION")) occlusion = atoi(e) != 0;
-  if (occlusion) {
-    {
-      pings::prof::Scope ps("occl_setup", st);
-      PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bucket, 0, sizeof(uint32_t) * (size_t)num_tiles * gs.occ_nb, st));
-      hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, st, P, gs.depth_key_sorted, gs.nvalid);
-      PINGS_LAUNCH_CHECK();
-    }
-    {
-      pings::prof::Scope ps("occl_budget", st);
-      hipLaunchKernelGGL(occl_budget_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
-                         gs.rec, gs.nvalid, num_tiles, gs.occ_bucket);
-      PINGS_LAUNCH_CHECK();
-    }
-    {
-      pings::prof::Scope ps("occl_scan", st);
-      hipLaunchKernelGGL(occl_scan_kernel, dim3(pings::ceil_div(num_tiles, 64)), dim3(512), 0, st, num_tiles,
-                         gs.occ_nb, gs.occ_bucket, gs.occ_bsat);
-      PINGS_LAUNCH_CHECK();
-    }
-  } else {
-    PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bsat, 0xFF, sizeof(uint16_t) * (size_t)num_tiles, st));
-    PINGS_HIP_CHECK(hipMemsetAsync(gs.nvalid, 0, sizeof(uint32_t), st));
-  }
-  {
-    pings::prof::Scope ps("tile_count_scan", st);
-    PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 2 * STAT_SHARDS * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(count_kept_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
-                       gs.occ_bsat, gs.nvalid, gs.tiles_sorted, gs.stats);
-    PINGS_LAUNCH_CHECK();
-    tb = gs.temp_bytes;
-    PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
-                                                     P, st));
-  }
+  bool library_sort = false;
+  if (const char* e = getenv("PINGS_DEPTH_SORT")) library_sort = e[0] == 'l';
   uint32_t total = 0;
   static thread_local unsigned long long shards[2 * STAT_SHARDS];
-  PINGS_HIP_CHECK(hipMemcpyAsync(&total, gs.offsets_sorted + (P - 1), sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipMemcpyAsync(shards, gs.stats, sizeof(shards), hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipStreamSynchronize(st));
+  for (;;) {
+    size_t tb = gs.temp_bytes;
+    if (library_sort) {
+      pings::prof::Scope ps("depth_sort", st);
+      PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(gs.temp, tb, gs.depth_key, gs.depth_key_sorted,
+                                                         gs.gidx, gs.gidx_sorted, P, 0, 32, st));
+      hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, st, P, gs.depth_key_sorted, gs.nvalid);
+      PINGS_LAUNCH_CHECK();
+    } else {
+      pings::prof::Scope ps("depth_sort", st);
+      PINGS_HIP_CHECK(hipMemsetAsync(gs.ds_head, 0, sizeof(uint32_t) * gs.ds_words, st));
+      hipLaunchKernelGGL(ds_minmax_kernel, dim3(std::min(pings::ceil_div(P, 256), 512)), block, 0, st, P,
+                         gs.depth_key, gs.ds_head);
+      PINGS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ds_range_kernel, dim3(1), dim3(64), 0, st, gs.ds_head);
+      PINGS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ds_hist_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_cnt);
+      PINGS_LAUNCH_CHECK();
+      PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(gs.temp, tb, gs.ds_cnt, gs.ds_off, DS_NB + (int)grid.x + 1, st));
+      hipLaunchKernelGGL(ds_scatter_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_off, gs.ds_fill,
+                         gs.depth_key_sorted, gs.ds_idx, gs.gidx_sorted);
+      PINGS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ds_rank_kernel, grid, block, 0, st, gs.depth_key_sorted, gs.ds_idx, gs.ds_head, gs.ds_off,
+                         gs.gidx_sorted, gs.nvalid);
+      PINGS_LAUNCH_CHECK();
+    }
+    if (occlusion) {
+      {
+        pings::prof::Scope ps("occl_setup", st);
+        PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bucket, 0, sizeof(uint32_t) * (size_t)num_tiles * gs.occ_nb, st));
+      }
+      {
+        pings::prof::Scope ps("occl_budget", st);
+        hipLaunchKernelGGL(occl_budget_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
+                           gs.rec, gs.nvalid, num_tiles, gs.occ_bucket);
+        PINGS_LAUNCH_CHECK();
+      }
+      {
+        pings::prof::Scope ps("occl_scan", st);
+        hipLaunchKernelGGL(occl_scan_kernel, dim3(pings::ceil_div(num_tiles, 64)), dim3(512), 0, st, num_tiles,
+                           gs.occ_nb, gs.occ_bucket, gs.occ_bsat);
+        PINGS_LAUNCH_CHECK();
+      }
+    } else {
+      PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bsat, 0xFF, sizeof(uint16_t) * (size_t)num_tiles, st));
+      PINGS_HIP_CHECK(hipMemsetAsync(gs.nvalid, 0, sizeof(uint32_t), st));
+    }
+    {
+      pings::prof::Scope ps("tile_count_scan", st);
+      PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 2 * STAT_SHARDS * sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(count_kept_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
+                         gs.occ_bsat, gs.nvalid, gs.tiles_sorted, gs.stats);
+      PINGS_LAUNCH_CHECK();
+      tb = gs.temp_bytes;
+      PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
+                                                       P, st));
+    }
+    uint32_t overflow = 0;
+    PINGS_HIP_CHECK(hipMemcpyAsync(&total, gs.offsets_sorted + (P - 1), sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+    PINGS_HIP_CHECK(hipMemcpyAsync(shards, gs.stats, sizeof(shards), hipMemcpyDeviceToHost, st));
+    if (!library_sort)
+      PINGS_HIP_CHECK(hipMemcpyAsync(&overflow, gs.ds_head + DS_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PINGS_HIP_CHECK(hipStreamSynchronize(st));
+    if (overflow == 0) break;
+    library_sort = true;  // a depth bucket overflowed: redo the frame with the library sort
+  }
   *num_instances = (int64_t)total;
   unsigned long long stats[2] = {0, 0};
   for (int i = 0; i < STAT_SHARDS; ++i) { stats[0] += shards[2 * i]; stats[1] += shards[2 * i + 1]; }

@@ -433,3 +433,47 @@ def test_occlusion_culling_changes_no_output_bit(mode, monkeypatch):
         assert torch.equal(a, b)
     o, *_ = _oracle(sc, torch.float64, mode, False)
     assert rel_err(out1[0], o["color"]) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["random_with_ties", "single_depth_plane"])
+def test_bucket_depth_sort_is_the_library_sort(scene, monkeypatch):
+    """The bucket depth sort (histogram over the key bits + rank among bucket mates) must give the stable order of
+    the library radix sort bit for bit: with equal depths (ties resolved by Gaussian index) and on a degenerate
+    cloud — 6000 Gaussians at exactly one depth overflow a bucket, the host re-runs the frame with the library
+    sort — every output and gradient is identical to a run with PINGS_DEPTH_SORT=library."""
+    from pings_amd import rasterizer as hr
+
+    W, H = 160, 96
+    sc = make_scene(6000, W, H, seed=123, surfel=True)
+    V = sc["cam"]["viewmatrix"].to(sc["means"].dtype)
+    pc = sc["means"] @ V[:3, :3] + V[3, :3]
+    if scene == "random_with_ties":
+        pc[:, 2] = torch.round(pc[:, 2].abs() * 8) / 8 + 1.0      # many exactly equal depths
+    else:
+        pc[:, 2] = 3.0
+    sc["means"] = (pc - V[3, :3]) @ torch.linalg.inv(V[:3, :3])
+
+    def run(which):
+        if which:
+            monkeypatch.setenv("PINGS_DEPTH_SORT", which)
+        else:
+            monkeypatch.delenv("PINGS_DEPTH_SORT", raising=False)
+        hs = hip_settings(sc, "surfel", False, 1.0)
+        rast = hr.SurfelGaussianRasterizer(hs)
+        leaves = [sc[k].to(torch.float32).cuda().contiguous().requires_grad_(True)
+                  for k in ("means", "col", "op", "scales", "rot")]
+        th = torch.zeros(3, device="cuda", requires_grad=True)
+        rh = torch.zeros(3, device="cuda", requires_grad=True)
+        out = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), colors_precomp=leaves[1],
+                   opacities=leaves[2], scales=leaves[3], rotations=leaves[4], theta=th, rho=rh)
+        imgs = [t for t in out if t.is_floating_point() and t.dim() == 3]
+        gg = torch.Generator(device="cuda").manual_seed(9)
+        torch.autograd.backward(imgs, [torch.randn(t.shape, generator=gg, device="cuda") for t in imgs])
+        return out, [t.grad for t in leaves] + [th.grad, rh.grad]
+
+    out_b, g_b = run(None)
+    out_l, g_l = run("library")
+    assert float(out_b[0].abs().sum()) > 0
+    for a, b in zip(list(out_b) + g_b, list(out_l) + g_l):
+        assert torch.equal(a, b)
