@@ -40,8 +40,11 @@ PINGS_API const char* pings_last_error(void);
 
 /* Per-stage HIP-event timing of everything this library launches (bench.py's roofline
  * figures).  pings_prof_report synchronises the device and writes "name count total_ms"
- * lines into a HOST buffer, then clears the record. */
+ * lines into a HOST buffer, then clears the record.  Each recorded stage costs two event packets on the stream
+ * (~10 us of idle time between dependent launches): pings_prof_only("stage") restricts the record to one stage
+ * (NULL / "" = all), which is what bench.py's timed region uses for the dominant kernel. */
 PINGS_API int pings_prof_enable(int on);
+PINGS_API int pings_prof_only(const char* stage);
 PINGS_API int pings_prof_report(char* buf, size_t cap);
 
 /* --------------------------------------------------------------- fused SSIM

@@ -27,6 +27,7 @@ struct Entry {
   hipEvent_t a, b;
 };
 bool g_on = false;
+std::string g_only;  // non-empty: record only the stage of this name
 std::vector<Entry> g_entries;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open_a = nullptr;
@@ -44,7 +45,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-bool enabled() { return g_on; }
+bool enabled(const char* name) { return g_on && (g_only.empty() || g_only == name); }
 
 void begin(const char* name, hipStream_t st) {
   g_open_a = get_event();
@@ -63,6 +64,11 @@ void end(hipStream_t st) {
 
 PINGS_API int pings_prof_enable(int on) {
   pings::prof::g_on = on != 0;
+  return PINGS_OK;
+}
+
+PINGS_API int pings_prof_only(const char* stage) {
+  pings::prof::g_only = stage ? stage : "";
   return PINGS_OK;
 }
 

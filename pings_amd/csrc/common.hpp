@@ -20,13 +20,13 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // Optional per-stage HIP-event timing (off by default; bench.py turns it on to get the
 // per-kernel durations its roofline figures are computed from).
 namespace prof {
-bool enabled();
+bool enabled(const char* name);
 void begin(const char* name, hipStream_t st);
 void end(hipStream_t st);
 struct Scope {
   hipStream_t st;
   bool on;
-  Scope(const char* name, hipStream_t s) : st(s), on(enabled()) { if (on) begin(name, st); }
+  Scope(const char* name, hipStream_t s) : st(s), on(enabled(name)) { if (on) begin(name, st); }
   ~Scope() { if (on) end(st); }
 };
 }  // namespace prof

@@ -187,14 +187,8 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     stream = _lib.stream_ptr(dev)
     geom = torch.empty(L.pings_raster_geom_bytes(P, H, W), **u8)
     radii = torch.zeros(P, dtype=torch.int32, device=dev)
-    n_inst = C.c_int64(0)
-    fclass = C.c_int32(1)
-    st = L.pings_raster_preprocess(prep.ref(), P, _lib.ptr(means3D), _lib.ptr(colors),
-                                   _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
-                                   _lib.ptr(geom), _lib.ptr(radii), C.byref(n_inst), C.byref(fclass), stream)
-    _lib.check(st, "pings_raster_preprocess")
-    I = int(n_inst.value)
-    binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
+    # everything that does not depend on the instance count is allocated BEFORE preprocess: that call ends in the
+    # frame's one host synchronisation, and the GPU idles from there until the render launches are issued
     image = torch.empty(L.pings_raster_image_bytes(H, W), **u8)
     color = torch.empty(3, H, W, **f32)
     depth = torch.empty(1, H, W, **f32)
@@ -205,9 +199,19 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     else:
         normal = None
         per_g = torch.zeros(P, dtype=torch.int32, device=dev)
-    st = L.pings_raster_render(prep.ref(), P, I, _lib.ptr(geom), _lib.ptr(binning), _lib.ptr(image),
-                               _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth),
-                               _lib.ptr(alpha), _lib.ptr(per_g), int(fclass.value), stream)
+    out_ptrs = (_lib.ptr(image), _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(per_g))
+    geom_ptr, ref = _lib.ptr(geom), prep.ref()
+    n_inst = C.c_int64(0)
+    fclass = C.c_int32(1)
+    st = L.pings_raster_preprocess(ref, P, _lib.ptr(means3D), _lib.ptr(colors),
+                                   _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
+                                   geom_ptr, _lib.ptr(radii), C.byref(n_inst), C.byref(fclass), stream)
+    if st:
+        _lib.check(st, "pings_raster_preprocess")
+    I = n_inst.value
+    binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
+    st = L.pings_raster_render(ref, P, I, geom_ptr, _lib.ptr(binning), out_ptrs[0], out_ptrs[1], out_ptrs[2],
+                               out_ptrs[3], out_ptrs[4], out_ptrs[5], fclass.value, stream)
     _lib.check(st, "pings_raster_render")
     fs = _ForwardState()
     fs.prep, fs.P, fs.I = prep, P, I
