@@ -13,7 +13,7 @@
 //                         one Gaussian are contiguous (slot order = depth rank order).
 //   row_chunk_sum_kernel  balanced first level of the per-Gaussian sum: one 16-lane group per
 //                         (Gaussian, chunk of <= 64 rows) pair, lane = column, streaming 64-B rows.
-//   gaussian_bwd_kernel   per Gaussian (in depth-rank order): adds its chunk partials, then chains
+//   gaussian_bwd_kernel   per Gaussian (in index order, rows located through its depth rank): adds its chunk partials, then chains
 //                         through conic / EWA projection / quaternion / scale / camera transform to
 //                         the input gradients and the pose-tangent terms (block-reduced, fixed order).
 //   tau_reduce_kernel     final fixed-order reduction of the pose-tangent partials.
@@ -648,22 +648,28 @@ __global__ __launch_bounds__(256) void row_chunk_sum_kernel(int P, const uint32_
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void gaussian_bwd_kernel(
     BParams p, const float* __restrict__ means3D, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const uint32_t* __restrict__ gidx_sorted,
+    const float* __restrict__ rotations, const uint4* __restrict__ rect, const uint32_t* __restrict__ rank_of,
     const uint32_t* __restrict__ tiles_sorted, const uint32_t* __restrict__ pair_off,
     const float* __restrict__ partials, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, float* __restrict__ tau_partials) {
   __shared__ float sTau[256 / 64][6];
-  const int rank = blockIdx.x * blockDim.x + threadIdx.x;
+  // one thread per Gaussian in INDEX order: parameters are read and gradients written coalesced; only the two
+  // words that locate the Gaussian's chunk partials go through its depth rank
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  if (rank < p.P) {
-    const int g = (int)gidx_sorted[rank];
-    const uint32_t n_tiles = tiles_sorted[rank];
+  if (g < p.P) {
+    uint32_t n_tiles = 0u, qa = 0u, qb = 0u;
+    if (rect[g].w != 0u) {  // survived culling: has a depth rank
+      const uint32_t rank = rank_of[g];
+      n_tiles = tiles_sorted[rank];
+      qa = pair_off[rank];
+      qb = pair_off[rank + 1];
+    }
     float G[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) G[k] = 0.f;
-    const uint32_t qa = pair_off[rank], qb = pair_off[rank + 1];
     const float4* prow = reinterpret_cast<const float4*>(partials);
     for (uint32_t k = qa; k < qb; ++k) {
 #pragma unroll
@@ -860,19 +866,21 @@ __global__ __launch_bounds__(256, 4) void gaussian_bwd_kernel(
 
 __global__ __launch_bounds__(256) void tau_reduce_kernel(const float* __restrict__ partials, int nblocks,
                                                           float* __restrict__ dL_dtau) {
-  __shared__ double sRed[256];
-  for (int k = 0; k < 6; ++k) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partials[(size_t)i * 6 + k];
-    sRed[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) sRed[threadIdx.x] += sRed[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) dL_dtau[k] = (float)sRed[0];
-    __syncthreads();
+  __shared__ double sRed[4][6];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += (double)partials[(size_t)i * 6 + k];
   }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+    if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6][k] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    dL_dtau[threadIdx.x] = (float)(((sRed[0][threadIdx.x] + sRed[1][threadIdx.x]) + sRed[2][threadIdx.x]) + sRed[3][threadIdx.x]);
 }
 
 }  // namespace raster
@@ -1042,12 +1050,12 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
     pings::prof::Scope ps_g("gaussian_bwd", st);
     if (s->mode == PINGS_RASTER_SURFEL)
       hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_SURFEL>, dim3(nblocks), block, 0, st, bp, means3D,
-                         scales, rotations, gs.gidx_sorted, gs.tiles_sorted, bw.pair_off, bw.partials,
+                         scales, rotations, gs.rect, gs.rank_of, gs.tiles_sorted, bw.pair_off, bw.partials,
                          dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dscales,
                          dL_drotations, bw.tau_partials);
     else
       hipLaunchKernelGGL(gaussian_bwd_kernel<MODE_3DGS>, dim3(nblocks), block, 0, st, bp, means3D,
-                         scales, rotations, gs.gidx_sorted, gs.tiles_sorted, bw.pair_off, bw.partials,
+                         scales, rotations, gs.rect, gs.rank_of, gs.tiles_sorted, bw.pair_off, bw.partials,
                          dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacities, dL_dscales,
                          dL_drotations, bw.tau_partials);
     PINGS_LAUNCH_CHECK();

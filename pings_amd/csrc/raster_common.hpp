@@ -71,6 +71,7 @@ struct GeomState {
   float4* rec;
   uint4* rect;
   uint32_t *depth_key, *depth_key_sorted, *gidx, *gidx_sorted;
+  uint32_t* rank_of;                        // [P] depth rank of each surviving Gaussian (inverse of gidx_sorted)
   uint32_t *tiles_sorted, *offsets_sorted;  // per depth rank: KEPT tiles of the Gaussian and their inclusive scan
   uint32_t* occ_bucket;                     // [occ_nb][num_tiles] fixed-point opacity budget per (rank bucket, tile)
   uint16_t* occ_bsat;                       // [num_tiles] last rank bucket a tile still needs (0xFFFF = all)

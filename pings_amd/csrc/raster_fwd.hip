@@ -74,6 +74,7 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.depth_key_sorted = c.take<uint32_t>(n);
   g.gidx = c.take<uint32_t>(n);
   g.gidx_sorted = c.take<uint32_t>(n);
+  g.rank_of = c.take<uint32_t>(n);
   g.tiles_sorted = c.take<uint32_t>(n);
   g.offsets_sorted = c.take<uint32_t>(n);
   g.occ_nb = occlusion_buckets((int)nt);
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(256) void ds_scatter_kernel(int P, const uint32_t* 
 
 __global__ __launch_bounds__(256) void ds_rank_kernel(const uint32_t* __restrict__ tmp_key, const uint32_t* __restrict__ tmp_idx,
                                                        uint32_t* __restrict__ head, const uint32_t* __restrict__ off,
-                                                       uint32_t* __restrict__ gidx_sorted, uint32_t* __restrict__ nvalid) {
+                                                       uint32_t* __restrict__ gidx_sorted, uint32_t* __restrict__ rank_of,
+                                                       uint32_t* __restrict__ nvalid) {
   const uint32_t n = off[DS_NB];
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (s == 0u) *nvalid = n;
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256) void ds_rank_kernel(const uint32_t* __restrict
   const uint32_t lo = off[b], hi = off[b + 1];
   if (hi - lo > DS_LIMIT) {  // degenerate depth distribution: keep a valid permutation, let the host redo the sort
     gidx_sorted[s] = id;
+    rank_of[id] = s;
     if (s == lo) head[DS_FLAG] = 1u;
     return;
   }
@@ -486,6 +489,13 @@ __global__ __launch_bounds__(256) void ds_rank_kernel(const uint32_t* __restrict
     rank += (kt < k || (kt == k && it < id)) ? 1u : 0u;
   }
   gidx_sorted[lo + rank] = id;
+  rank_of[id] = lo + rank;
+}
+
+__global__ __launch_bounds__(256) void invert_perm_kernel(int P, const uint32_t* __restrict__ gidx_sorted,
+                                                           uint32_t* __restrict__ rank_of) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < P) rank_of[gidx_sorted[r]] = (uint32_t)r;
 }
 
 // ranks [0, nvalid) hold the Gaussians with a real depth key (culled ones sort last): first culled rank,
@@ -1277,6 +1287,8 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                                                          gs.gidx, gs.gidx_sorted, P, 0, 32, st));
       hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(64), 0, st, P, gs.depth_key_sorted, gs.nvalid);
       PINGS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(invert_perm_kernel, grid, block, 0, st, P, gs.gidx_sorted, gs.rank_of);
+      PINGS_LAUNCH_CHECK();
     } else {
       pings::prof::Scope ps("depth_sort", st);
       PINGS_HIP_CHECK(hipMemsetAsync(gs.ds_head, 0, sizeof(uint32_t) * gs.ds_words, st));
@@ -1292,7 +1304,7 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                          gs.depth_key_sorted, gs.ds_idx, gs.gidx_sorted);
       PINGS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ds_rank_kernel, grid, block, 0, st, gs.depth_key_sorted, gs.ds_idx, gs.ds_head, gs.ds_off,
-                         gs.gidx_sorted, gs.nvalid);
+                         gs.gidx_sorted, gs.rank_of, gs.nvalid);
       PINGS_LAUNCH_CHECK();
     }
     if (occlusion) {
