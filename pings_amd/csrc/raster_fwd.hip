@@ -275,6 +275,14 @@ __device__ inline int strided_rank(int P) {
   return r < P ? r : -1;
 }
 
+// value of `v` in lane `src`, `src` wave-uniform: v_readlane_b32 (scalar path) instead of the ds_bpermute_b32 a
+// general __shfl compiles to — no LDS round trip, no lgkmcnt wait in the per-rectangle loops below
+__device__ inline int lane_value(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ inline uint32_t lane_value(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ inline float lane_value(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+
 constexpr int SMALL_RECT = 8;
 constexpr int STAT_SHARDS = 256;
 
@@ -299,8 +307,8 @@ __device__ inline void walk_rects(const RectLane& me, int gx, Serial serial, Coo
   while (m) {
     const int src = __ffsll((long long)m) - 1;
     m &= m - 1;
-    const uint32_t n = (uint32_t)__shfl((int)me.n, src, 64);
-    const int x0 = __shfl(me.xmin, src, 64), y0 = __shfl(me.ymin, src, 64), wdt = __shfl(me.wdt, src, 64);
+    const uint32_t n = lane_value(me.n, src);
+    const int x0 = lane_value(me.xmin, src), y0 = lane_value(me.ymin, src), wdt = lane_value(me.wdt, src);
     const float inv_w = 1.0f / (float)wdt;
     coop_begin(src);
     for (uint32_t k0 = 0; k0 < n; k0 += 64) {
@@ -550,9 +558,9 @@ __global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
   walk_rects(
       me, gx, [&](int tx, int ty) { add(tx, ty, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, bk); },
       [&](int src) {
-        smx = __shfl(ra.x, src, 64); smy = __shfl(ra.y, src, 64); so = __shfl(ra.z, src, 64);
-        scx = __shfl(rb.x, src, 64); scy = __shfl(rb.y, src, 64); scz = __shfl(rb.z, src, 64);
-        sb = (uint32_t)__shfl((int)bk, src, 64);
+        smx = lane_value(ra.x, src); smy = lane_value(ra.y, src); so = lane_value(ra.z, src);
+        scx = lane_value(rb.x, src); scy = lane_value(rb.y, src); scz = lane_value(rb.z, src);
+        sb = lane_value(bk, src);
       },
       [&](int, int tx, int ty, bool act) { if (act) add(tx, ty, smx, smy, so, scx, scy, scz, sb); });
 }
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(256) void count_kept_kernel(int P, int gx, int nb,
         if (cur >= 0 && lane == cur) kept = acc;
         cur = src;
         acc = 0;
-        sb = (uint32_t)__shfl((int)bk, src, 64);
+        sb = lane_value(bk, src);
       },
       [&](int, int tx, int ty, bool act) {
         acc += (uint32_t)__popcll(__ballot(act && sb <= (uint32_t)bsat[ty * gx + tx]));
@@ -662,9 +670,9 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int nb,
         }
       },
       [&](int src) {
-        sb = (uint32_t)__shfl((int)bk, src, 64);
-        so = (uint32_t)__shfl((int)o, src, 64);
-        sg = (uint32_t)__shfl((int)me.g, src, 64);
+        sb = lane_value(bk, src);
+        so = lane_value(o, src);
+        sg = lane_value(me.g, src);
       },
       [&](int, int tx, int ty, bool act) {
         const int tile = ty * gx + tx;
@@ -1119,6 +1127,7 @@ __global__ __launch_bounds__(256) void combine_quadrants_kernel(int64_t I, const
                                                                 uint32_t* __restrict__ inst_cnt,
                                                                 uint8_t* __restrict__ inst_qmask) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { inst_w[I] = 0.f; inst_qmask[I] = 0; }  // sentinel entry of the live-instance scans
   if (i >= I) return;
   const float4 w = wq[i];
   inst_w[i] = ((w.x + w.y) + w.z) + w.w;
@@ -1158,8 +1167,8 @@ __global__ __launch_bounds__(256) void per_gaussian_sum_kernel(
   while (m) {
     const int src = __ffsll((long long)m) - 1;
     m &= m - 1;
-    const uint32_t nb = (uint32_t)__shfl((int)n, src, 64);
-    const uint32_t bb = (uint32_t)__shfl((int)base, src, 64);
+    const uint32_t nb = lane_value(n, src);
+    const uint32_t bb = lane_value(base, src);
     T acc = (T)0, acc1 = (T)0, acc2 = (T)0, acc3 = (T)0;
     uint32_t k = lane;
     for (; k + 192 < nb; k += 256) {  // four independent loads in flight
@@ -1415,10 +1424,6 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
         hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, rg, dim3(256), 0, st, I,
                            (const uint32_t*)bs.tile_key_sorted, bs.ranges);
       PINGS_LAUNCH_CHECK();
-      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
-      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));
-      if (s->mode == PINGS_RASTER_3DGS)
-        PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st));
     }
   }
   {
@@ -1428,6 +1433,12 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   // PINGS_BLEND_PPL = 1 | 2 selects the workgroup-per-tile kernel with that many pixels per lane (A/B runs, tests)
   int ppl = 0;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
+  if (I > 0 && ppl != 0) {  // the workgroup-per-tile kernels accumulate into zeroed per-instance sums
+    PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
+    PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));
+    if (s->mode == PINGS_RASTER_3DGS)
+      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st));
+  }
   // exact per-quadrant masks are needed iff the backward pass of this view will run the Gaussian-per-lane kernel
   // (same predicate as pings_raster_backward: footprint class, PINGS_BLEND_BWD override); they only cost something
   // in the 2-pixels-per-lane forward
