@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
 //      trip through the wave's private LDS to become A operands, B = x / gY read column-wise from global memory;
 //      gb1 falls out of the transposed gH^T fragments, gb2 of the gY columns.
 // 324 MFMAs per tile.  Weight-gradient accumulators stay in registers across the wave's tiles (8 x 16 + 5 VGPRs),
-// are written as per-WAVE partials and summed by mlp_reduce_kernel in fixed order: bitwise reproducible.
+// are added across the four waves in LDS (wave order) and written as one partial per workgroup, summed by
+// mlp_reduce_kernel in fixed order: bitwise reproducible.
 constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
                                                               const float* __restrict__ gy, const float* __restrict__ W1,
@@ -612,25 +613,36 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
     }
   }
 
-  // ---- this wave's partial weight gradients
-  float* P = partials + ((size_t)blockIdx.x * 4 + wave) * per_block;
-  float* pW1 = P;
-  float* pW2 = pW1 + (size_t)128 * IN;
-  float* pB1 = pW2 + (size_t)OUT * 128;
-  float* pB2 = pB1 + 128;
+  // ---- the workgroup's partial weight gradients: the four waves add theirs in wave order into the (now dead)
+  // weight images, which already have the conflict-free layouts [hid][33] and [o][129]; one partial per workgroup
+  float* sB = &sT[0][0][0];  // gb1[128], gb2[32]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int hb = 0; hb < 4; ++hb) {
+      for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int hid = hb * 32 + rowmap(q, h);
-      if (r < OUT) pW2[(size_t)r * 128 + hid] = aW2T[hb][q];   // lane = o
-      if (r < IN) pW1[(size_t)hid * IN + r] = aW1[hb][q];      // lane = i
+        for (int q = 0; q < 16; ++q) {
+          const int hid = hb * 32 + rowmap(q, h);
+          float* d2 = &sW2[r * 129 + hid];     // lane = o
+          float* d1 = &sW1[hid * BW_LD + r];   // lane = i
+          if (w == 0) { *d2 = aW2T[hb][q]; *d1 = aW1[hb][q]; }
+          else { *d2 += aW2T[hb][q]; *d1 += aW1[hb][q]; }
+        }
+        const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);  // the two row halves of hidden unit hb*32 + r
+        if (h == 0) { if (w == 0) sB[hb * 32 + r] = v; else sB[hb * 32 + r] += v; }
+      }
+      const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
+      if (h == 0) { if (w == 0) sB[128 + r] = v2; else sB[128 + r] += v2; }
     }
-    const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);      // the two row halves of hidden unit hb*32 + r
-    if (h == 0) pB1[hb * 32 + r] = v;
   }
-  const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
-  if (h == 0 && r < OUT) pB2[r] = v2;
+  __syncthreads();
+  float* P = partials + (size_t)blockIdx.x * per_block;
+  const int nW1 = 128 * IN, nW2 = OUT * 128;
+  for (int e = tid; e < nW1; e += 256) P[e] = sW1[(e / IN) * BW_LD + (e % IN)];
+  for (int e = tid; e < nW2; e += 256) P[nW1 + e] = sW2[(e >> 7) * 129 + (e & 127)];
+  if (tid < 128) P[nW1 + nW2 + tid] = sB[tid];
+  if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sB[128 + tid];
 }
 
 __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblocks, size_t per_block, int IN,
@@ -750,7 +762,7 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
                        dL_dx, reinterpret_cast<float*>(scratch), per_block);
     PINGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
-                       st, reinterpret_cast<const float*>(scratch), grid_w * 4, per_block, IN, HID, OUT, dL_dW1,
+                       st, reinterpret_cast<const float*>(scratch), grid_w, per_block, IN, HID, OUT, dL_dW1,
                        dL_db1, dL_dW2, dL_db2);
     PINGS_LAUNCH_CHECK();
     return PINGS_OK;
