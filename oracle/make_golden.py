@@ -461,8 +461,47 @@ def make_imgloss(R):
         print(f"imgloss_{name}: l1 {l1.item():.4f} depth {dl.item():.4f} consist {cons.item():.4f} valid depth {int(ok.sum())} normals {int(okn.sum())}")
 
 
+# ---------------------------------------------------------------- G11 mesher bulk query
+def make_mesher(R):
+    """G11: `Mesher.get_query_from_bbx` + `Mesher.query_points` (utils/mesher.py:40-212) over the maps of G1-G3: a
+    marching-cubes grid around a corner of the map (most of it empty space), global query, numpy outputs."""
+    import types
+    from unittest.mock import MagicMock
+
+    for m in ("skimage", "skimage.measure"):   # marching cubes itself is not on the path; not installed here
+        sys.modules.setdefault(m, MagicMock())
+    import utils.mesher as M  # type: ignore
+
+    out = {}
+    for name in ("gs_f32", "pin_f8"):
+        kw = SDF_CASES[name]
+        cfg, npm = build_reference_map(R, kw, seed=len(name), after_pgo=False)
+        g2 = torch.Generator().manual_seed(99)
+        dec = R.Decoder(cfg, cfg.feature_dim, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, 1)
+        with torch.no_grad():
+            for p_ in dec.parameters():
+                p_.copy_(torch.randn(p_.shape, generator=g2) * 0.3)
+        ref = np.load(OUT / f"sdf_{name}.npz")
+        assert np.array_equal(_np(dec.layers[0].weight), ref["dec.layers.0.weight"]), "G11 must reuse the decoder of sdf_*.npz"
+        fake = types.SimpleNamespace(neural_points=npm, sdf_mlp=dec, sem_mlp=None, color_mlp=None, config=cfg,
+                                     device="cpu", cur_device="cpu", dtype=torch.float32)
+        pts = npm.neural_points
+        lo = pts.min(0)[0].double().numpy()
+        hi = lo + np.array([3.1, 2.6, 2.2])
+        bbx = types.SimpleNamespace(get_min_bound=lambda lo=lo: lo.copy(), get_max_bound=lambda hi=hi: hi.copy())
+        vs = 0.6 * cfg.voxel_size_m
+        coord, num, origin = M.Mesher.get_query_from_bbx(fake, bbx, vs, pad_voxel=1, skip_top_voxel=1)
+        sdf, _, _, mask = M.Mesher.query_points(fake, coord, 500, True, False, False, True, query_locally=False,
+                                                mask_min_nn_count=4)
+        out.update({f"{name}_min": lo, f"{name}_max": hi, f"{name}_voxel": np.float64(vs), f"{name}_coord": _np(coord),
+                    f"{name}_num": num, f"{name}_origin": origin, f"{name}_sdf": sdf, f"{name}_mask": mask})
+        print(f"mesher {name}: grid {num.tolist()} = {coord.shape[0]} points, mc_mask {int(mask.sum())}, "
+              f"with neighbours {int((sdf != 0).sum())}")
+    np.savez_compressed(OUT / "mesher_grid.npz", **out)
+
+
 GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map,
-          "tracker": make_tracker, "imgloss": make_imgloss}
+          "tracker": make_tracker, "imgloss": make_imgloss, "mesher": make_mesher}
 
 
 def main(argv):
