@@ -645,6 +645,161 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
   if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sB[128 + tid];
 }
 
+// ---------------------------------------------------------------- backward of the SDF decoder shape: HID = 64, OUT = 1
+// (`Decoder.sdf`, decoder.py:102-104: [B k, F + 3] -> 64 -> 1; F + 3 = 35 or 11).  Same wave-per-tile scheme as
+// mlp_bwd_wave_kernel, specialised for the single output: gH^T = relu'(pre) * W2[hid] * gy[row] is elementwise in the
+// accumulator layout, gW2 / gb1 / gb2 accumulate per lane over all of the wave's tiles (one cross-lane reduction at
+// the very end), and only gH^T makes the LDS trip for gW1 += gH^T x.  Inputs are consumed two per MFMA step
+// (k = 2 s + h), so IN = 35 costs 18 steps of product A instead of a padded 32.  NS = k-steps, IB = 32-wide input
+// blocks.  Per tile and hidden block: NS + 1 (A) + 16 IB (C) + 16 IB (D) MFMAs.
+template <int NS, int IB>
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N, int IN, const float* __restrict__ x,
+                                                                    const float* __restrict__ gy,
+                                                                    const float* __restrict__ W1,
+                                                                    const float* __restrict__ b1,
+                                                                    const float* __restrict__ W2, float* __restrict__ gx,
+                                                                    float* __restrict__ partials, size_t per_block) {
+  constexpr int LD1 = 32 * IB + 1;
+  __shared__ float sW1[64 * LD1];          // W1[hid][i], zero beyond IN; reused for the workgroup's gW1
+  __shared__ float sG[4][32 * BW_LD];      // per wave: gH^T as [hid_local][row]
+  __shared__ float sB[64 + 64 + 1];        // workgroup sums of gW2, gb1, gb2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 64 * 32 * IB; e += 256) {
+    const int j = e / (32 * IB), i = e - j * (32 * IB);
+    sW1[j * LD1 + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
+  }
+  float b1f[2], w2f[2][16];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w2f[hb][q] = W2[hb * 32 + rowmap(q, h)];
+  }
+  __syncthreads();
+
+  f32x16 aW1[2][IB];
+  float aW2[2][16], aB1[2][16], aB2 = 0.f;
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      aW2[hb][q] = 0.f;
+      aB1[hb][q] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) aW1[hb][ib][q] = 0.f;
+    }
+  }
+  float* myG = &sG[wave][0];
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const float one = h == 0 ? 1.f : 0.f;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += nwaves) {
+    const long long row = t * 32 + r;
+    const bool ok = row < N;
+    float xf[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) xf[s2] = (ok && 2 * s2 + h < IN) ? x[(size_t)row * IN + 2 * s2 + h] : 0.f;
+    const float gyr = ok ? gy[row] : 0.f;
+    float xcol[IB][16];  // x[row = 16 h + s][column = 32 ib + r]
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const long long rc = t * 32 + 16 * h + s2;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+        xcol[ib][s2] = (rc < N && 32 * ib + r < IN) ? x[(size_t)rc * IN + 32 * ib + r] : 0.f;
+    }
+    aB2 += h == 0 ? gyr : 0.f;
+    f32x16 gxacc[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) gxacc[ib] = f32x16{0};
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      f32x16 pre = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) pre = mfma(sW1[(hb * 32 + r) * LD1 + 2 * s2 + h], xf[s2], pre);
+      pre = mfma(b1f[hb], one, pre);
+      float gH[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        gH[q] = pre[q] > 0.f ? w2f[hb][q] * gyr : 0.f;
+        aW2[hb][q] = fmaf(fmaxf(pre[q], 0.f), gyr, aW2[hb][q]);
+        aB1[hb][q] += gH[q];
+      }
+      if (gx) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            gxacc[ib] = mfma(sW1[(hb * 32 + rowmap(q, h)) * LD1 + 32 * ib + r], gH[q], gxacc[ib]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) myG[rowmap(q, h) * BW_LD + r] = gH[q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float aG = myG[r * BW_LD + 16 * h + s2];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) aW1[hb][ib] = mfma(aG, xcol[ib][s2], aW1[hb][ib]);
+      }
+    }
+    if (gx && ok) {
+      float* dst = gx + (size_t)row * IN;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = 32 * ib + rowmap(q, h);
+          if (i < IN) dst[i] = gxacc[ib][q];
+        }
+    }
+  }
+
+  // per-lane sums over rows -> sums over the 32 lanes that share h (hidden unit hb*32 + rowmap(q, h))
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        aW2[hb][q] += __shfl_xor(aW2[hb][q], off, 64);
+        aB1[hb][q] += __shfl_xor(aB1[hb][q], off, 64);
+      }
+    }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) aB2 += __shfl_xor(aB2, off, 64);
+
+  // the four waves add theirs in wave order: gW1 into the (now dead) W1 image, the vectors into sB
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int hid = hb * 32 + rowmap(q, h);
+#pragma unroll
+          for (int ib = 0; ib < IB; ++ib) {
+            float* d1 = &sW1[hid * LD1 + 32 * ib + r];
+            if (w == 0) *d1 = aW1[hb][ib][q]; else *d1 += aW1[hb][ib][q];
+          }
+          if (r == 0) {
+            if (w == 0) { sB[hid] = aW2[hb][q]; sB[64 + hid] = aB1[hb][q]; }
+            else { sB[hid] += aW2[hb][q]; sB[64 + hid] += aB1[hb][q]; }
+          }
+        }
+      if (lane == 0) { if (w == 0) sB[128] = aB2; else sB[128] += aB2; }
+    }
+  }
+  __syncthreads();
+  float* P = partials + (size_t)blockIdx.x * per_block;  // [64 IN | 64 | 64 | 1]
+  const int nW1 = 64 * IN;
+  for (int e = tid; e < nW1; e += 256) P[e] = sW1[(e / IN) * LD1 + (e % IN)];
+  if (tid < 64) { P[nW1 + tid] = sB[tid]; P[nW1 + 64 + tid] = sB[64 + tid]; }
+  if (tid == 0) P[nW1 + 128] = sB[128];
+}
+
 __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblocks, size_t per_block, int IN,
                                   int HID, int OUT, float* __restrict__ gW1, float* __restrict__ gb1,
                                   float* __restrict__ gW2, float* __restrict__ gb2) {
@@ -760,6 +915,25 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
     const int grid_w = (int)(want < 256 ? want : 256);     // one workgroup (four independent waves) per CU
     hipLaunchKernelGGL(mlp_bwd_wave_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, IN, OUT, x, dL_dy, W1, b1, W2,
                        dL_dx, reinterpret_cast<float*>(scratch), per_block);
+    PINGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
+                       st, reinterpret_cast<const float*>(scratch), grid_w, per_block, IN, HID, OUT, dL_dW1,
+                       dL_db1, dL_dW2, dL_db2);
+    PINGS_LAUNCH_CHECK();
+    return PINGS_OK;
+  }
+  if (HID == 64 && OUT == 1 && getenv("PINGS_MLP_BWD_WG") == nullptr) {
+    pings::prof::Scope ps("mlp_bwd", st);
+    const long long want = (ntiles + 3) / 4;
+    const int grid_w = (int)(want < 256 ? want : 256);
+#define PINGS_H64O1(NS_, IB_)                                                                                   \
+  hipLaunchKernelGGL((mlp_bwd_wave_h64o1_kernel<NS_, IB_>), dim3(grid_w), dim3(256), 0, st, (long long)N, IN, x, \
+                     dL_dy, W1, b1, W2, dL_dx, reinterpret_cast<float*>(scratch), per_block)
+    if (IN <= 12) PINGS_H64O1(6, 1);
+    else if (IN <= 32) PINGS_H64O1(16, 1);
+    else if (IN <= 36) PINGS_H64O1(18, 2);
+    else PINGS_H64O1(32, 2);
+#undef PINGS_H64O1
     PINGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
                        st, reinterpret_cast<const float*>(scratch), grid_w, per_block, IN, HID, OUT, dL_dW1,

@@ -6,7 +6,8 @@ from conftest import rel_err
 
 # (N, IN, HID, OUT): the five GS decoders (pings.py:156-160), the SDF decoder, ragged / tiny sizes
 SHAPES = [(1000, 32, 128, 24), (777, 32, 128, 32), (4096, 33, 128, 8), (513, 19, 128, 24), (300, 16, 128, 24),
-          (2048, 35, 64, 1), (31, 11, 64, 1), (1, 8, 32, 3), (70000, 32, 128, 24)]
+          (2048, 35, 64, 1), (31, 11, 64, 1), (5000, 20, 64, 1), (333, 64, 64, 1), (100001, 35, 64, 1), (1, 8, 32, 3),
+          (70000, 32, 128, 24)]
 
 
 def _ref(x, W1, b1, W2, b2):
@@ -24,6 +25,12 @@ def test_fused_mlp_forward_backward(shape):
     W1, b1 = torch.randn(HID, IN, generator=g) / IN ** 0.5, 0.2 * torch.randn(HID, generator=g)
     W2, b2 = torch.randn(OUT, HID, generator=g) / HID ** 0.5, 0.2 * torch.randn(OUT, generator=g)
     gy = torch.randn(N, OUT, generator=g)
+    for _ in range(4):  # rows with a pre-activation within fp32 rounding of the ReLU kink have no gradient to compare
+        kink = ((x.double() @ W1.double().T + b1.double()).abs() < 1e-5).any(dim=1)
+        if not kink.any():
+            break
+        x[kink] += 0.01
+    assert not kink.any()
     ref_in = [t.double().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
     yr = _ref(*ref_in)
     gr = torch.autograd.grad(yr, ref_in, gy.double())
