@@ -652,40 +652,43 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
 // the very end), and only gH^T makes the LDS trip for gW1 += gH^T x.  Inputs are consumed two per MFMA step
 // (k = 2 s + h), so IN = 35 costs 18 steps of product A instead of a padded 32.  NS = k-steps, IB = 32-wide input
 // blocks.  Per tile and hidden block: NS + 1 (A) + 16 IB (C) + 16 IB (D) MFMAs.
-template <int NS, int IB>
+template <int NS, int IB, int NT>
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N, int IN, const float* __restrict__ x,
                                                                     const float* __restrict__ gy,
                                                                     const float* __restrict__ W1,
                                                                     const float* __restrict__ b1,
                                                                     const float* __restrict__ W2, float* __restrict__ gx,
                                                                     float* __restrict__ partials, size_t per_block) {
-  constexpr int LD1 = 32 * IB + 1;
+  constexpr int WI = 32 * IB + NT;          // input columns held in the W1 image
+  constexpr int LD1 = WI | 1;               // odd leading dimension: conflict-free in both orientations
+  static_assert(NT == 0 || IB == 1, "tail inputs follow a single 32-wide block");
   __shared__ float sW1[64 * LD1];          // W1[hid][i], zero beyond IN; reused for the workgroup's gW1
   __shared__ float sG[4][32 * BW_LD];      // per wave: gH^T as [hid_local][row]
   __shared__ float sB[64 + 64 + 1];        // workgroup sums of gW2, gb1, gb2
+  __shared__ float sW2[64];                // W2[0][hid]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 64 * 32 * IB; e += 256) {
-    const int j = e / (32 * IB), i = e - j * (32 * IB);
+  for (int e = tid; e < 64 * WI; e += 256) {
+    const int j = e / WI, i = e - j * WI;
     sW1[j * LD1 + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
   }
-  float b1f[2], w2f[2][16];
+  if (tid < 64) sW2[tid] = W2[tid];
+  float b1f[2];
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
-    b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) w2f[hb][q] = W2[hb * 32 + rowmap(q, h)];
-  }
+  for (int hb = 0; hb < 2; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
   __syncthreads();
 
   f32x16 aW1[2][IB];
   float aW2[2][16], aB1[2][16], aB2 = 0.f;
+  float aT[NT > 0 ? NT : 1][2][16];  // gW1 of the NT tail inputs: per-lane sums over rows, like aW2 / aB1
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       aW2[hb][q] = 0.f;
       aB1[hb][q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) aT[j][hb][q] = 0.f;
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib) aW1[hb][ib][q] = 0.f;
     }
@@ -695,6 +698,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
   const long long nwaves = (long long)gridDim.x * 4;
   const float one = h == 0 ? 1.f : 0.f;
   for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += nwaves) {
+    // (a register prefetch of the next tile's operands, as in mlp_bwd_wave_kernel, measured 12 % SLOWER here)
+    asm volatile("" ::: "memory");  // keep the loop-invariant LDS operands in LDS (hoisting them costs ~100 VGPRs)
     const long long row = t * 32 + r;
     const bool ok = row < N;
     float xf[NS];
@@ -710,6 +715,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
         xcol[ib][s2] = (rc < N && 32 * ib + r < IN) ? x[(size_t)rc * IN + 32 * ib + r] : 0.f;
     }
     aB2 += h == 0 ? gyr : 0.f;
+    // tail inputs 32 .. 32 + NT - 1 of this lane's row (xf holds the inputs of parity h: fetch the others from the
+    // lane of the other half, same row) and their gX, both on the vector ALU: a second 32-wide MFMA block for three
+    // position inputs would double products C and D
+    float xt[NT > 0 ? NT : 1], gxt[NT > 0 ? NT : 1];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float own = xf[16 + j / 2], other = __shfl_xor(own, 32, 64);
+      xt[j] = (j & 1) == h ? own : other;
+      gxt[j] = 0.f;
+    }
     f32x16 gxacc[IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) gxacc[ib] = f32x16{0};
@@ -722,9 +737,14 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
       float gH[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        gH[q] = pre[q] > 0.f ? w2f[hb][q] * gyr : 0.f;
+        gH[q] = pre[q] > 0.f ? sW2[hb * 32 + rowmap(q, h)] * gyr : 0.f;
         aW2[hb][q] = fmaf(fmaxf(pre[q], 0.f), gyr, aW2[hb][q]);
         aB1[hb][q] += gH[q];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          aT[j][hb][q] = fmaf(gH[q], xt[j], aT[j][hb][q]);
+          gxt[j] = fmaf(sW1[(hb * 32 + rowmap(q, h)) * LD1 + 32 + j], gH[q], gxt[j]);
+        }
       }
       if (gx) {
 #pragma unroll
@@ -754,6 +774,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
           if (i < IN) dst[i] = gxacc[ib][q];
         }
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float v = gxt[j] + __shfl_xor(gxt[j], 32, 64);  // the two halves hold disjoint hidden units
+      if (gx && ok && h == 0 && 32 + j < IN) gx[(size_t)row * IN + 32 + j] = v;
+    }
   }
 
   // per-lane sums over rows -> sums over the 32 lanes that share h (hidden unit hb*32 + rowmap(q, h))
@@ -765,6 +790,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
       for (int off = 16; off > 0; off >>= 1) {
         aW2[hb][q] += __shfl_xor(aW2[hb][q], off, 64);
         aB1[hb][q] += __shfl_xor(aB1[hb][q], off, 64);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) aT[j][hb][q] += __shfl_xor(aT[j][hb][q], off, 64);
       }
     }
 #pragma unroll
@@ -787,6 +814,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
           if (r == 0) {
             if (w == 0) { sB[hid] = aW2[hb][q]; sB[64 + hid] = aB1[hb][q]; }
             else { sB[hid] += aW2[hb][q]; sB[64 + hid] += aB1[hb][q]; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              if (w == 0) sW1[hid * LD1 + 32 + j] = aT[j][hb][q]; else sW1[hid * LD1 + 32 + j] += aT[j][hb][q];
+            }
           }
         }
       if (lane == 0) { if (w == 0) sB[128] = aB2; else sB[128] += aB2; }
@@ -926,13 +957,13 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
     pings::prof::Scope ps("mlp_bwd", st);
     const long long want = (ntiles + 3) / 4;
     const int grid_w = (int)(want < 256 ? want : 256);
-#define PINGS_H64O1(NS_, IB_)                                                                                   \
-  hipLaunchKernelGGL((mlp_bwd_wave_h64o1_kernel<NS_, IB_>), dim3(grid_w), dim3(256), 0, st, (long long)N, IN, x, \
+#define PINGS_H64O1(NS_, IB_, NT_)                                                                                 \
+  hipLaunchKernelGGL((mlp_bwd_wave_h64o1_kernel<NS_, IB_, NT_>), dim3(grid_w), dim3(256), 0, st, (long long)N, IN, x, \
                      dL_dy, W1, b1, W2, dL_dx, reinterpret_cast<float*>(scratch), per_block)
-    if (IN <= 12) PINGS_H64O1(6, 1);
-    else if (IN <= 32) PINGS_H64O1(16, 1);
-    else if (IN <= 36) PINGS_H64O1(18, 2);
-    else PINGS_H64O1(32, 2);
+    if (IN <= 12) PINGS_H64O1(6, 1, 0);
+    else if (IN <= 32) PINGS_H64O1(16, 1, 0);
+    else if (IN <= 36) PINGS_H64O1(18, 2, 0);   // <18, 1, 3> (tail inputs on the vector ALU) measured no faster
+    else PINGS_H64O1(32, 2, 0);
 #undef PINGS_H64O1
     PINGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,

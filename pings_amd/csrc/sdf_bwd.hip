@@ -92,32 +92,75 @@ __global__ __launch_bounds__(64 * WPB) void sdf_gather_kernel(
   }
 }
 
-// One 32-lane group per SORTED POSITION: the group at the head of a run (first position, or a key different from
-// its predecessor's) sums the run's source rows (first F of `ld` floats, times the pair weight) in sorted order
-// and stores the destination row once; every other group leaves at once.  No list of run starts is built: a
-// compaction through one global cursor costs ~12 ns per returning atomic on this part (140 us for 0.5 M runs),
-// more than the whole summation.  Pair weights are addressed by the ORIGINAL pair id, carried in `pair_sorted`.
+// A wave takes 64 consecutive SORTED POSITIONS: each lane tests whether its position heads a run (first position,
+// or a key different from its predecessor's), and the wave's two 32-lane halves then work through the heads found
+// (ballot), one run each at a time: the half sums the run's source rows (first F of `ld` floats, times the pair
+// weight) in sorted order and stores the destination row once.  No list of run starts is built — a compaction
+// through one global cursor costs ~12 ns per returning atomic on this part (140 us for 0.5 M runs) — and no thread is
+// launched just to find out that it is not a head.  Pair weights are addressed by the ORIGINAL pair id
+// (`pair_sorted`).
 __global__ __launch_bounds__(256) void seg_sum_kernel(const unsigned* __restrict__ keys,
                                                        const unsigned* __restrict__ pair_sorted, long long n,
                                                        unsigned invalid_key, int F, int ld,
                                                        const unsigned* __restrict__ src_row,
                                                        const float* __restrict__ pair_w,
                                                        const float* __restrict__ rows, float* __restrict__ out) {
-  const int c = threadIdx.x & 31;
-  long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  if (p >= n) return;
-  const unsigned k = keys[p];
-  if (k == invalid_key || (p > 0 && keys[p - 1] == k)) return;
-  float a0 = 0.f, a1 = 0.f;
-  for (; p < n && keys[p] == k; ++p) {
-    const unsigned pr = pair_sorted[p];
-    const size_t r = (size_t)src_row[pr] * ld;
-    const float w = pair_w[pr];
-    if (c < F) a0 = fmaf(w, rows[r + c], a0);
-    if (c + 32 < F) a1 = fmaf(w, rows[r + c + 32], a1);
+  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
+  const long long base = ((long long)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL;
+  const long long mine = base + lane;
+  // every lane resolves ITS position (key -> pair -> source row, weight) up front: one dependent-load chain for the
+  // whole wave instead of one per summed row; the run loops below fetch these through cross-lane reads
+  unsigned kme = invalid_key, srme = 0u;
+  float wme = 0.f;
+  bool head = false;
+  if (mine < n) {
+    kme = keys[mine];
+    head = kme != invalid_key && (mine == 0 || keys[mine - 1] != kme);
+    const unsigned pr = pair_sorted[mine];
+    srme = src_row[pr];
+    wme = pair_w[pr];
   }
-  if (c < F) out[(size_t)k * F + c] = a0;
-  if (c + 32 < F) out[(size_t)k * F + c + 32] = a1;
+  unsigned long long m = __ballot(head);
+  while (m) {
+    // the two lowest heads: half 0 takes the first, half 1 the second (if any)
+    const int h0 = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    int h1 = -1;
+    if (m) { h1 = __ffsll((long long)m) - 1; m &= m - 1; }
+    // run keys and lengths inside this wave's 64 positions (sorted: the lanes holding a key are contiguous from its
+    // head); everything wave-uniform, so that the cross-lane reads below run with all lanes enabled
+    const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)kme, h0);
+    const unsigned k1 = h1 >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)kme, h1) : invalid_key;
+    const int len0 = __popcll(__ballot(kme == k0)), len1 = h1 >= 0 ? __popcll(__ballot(kme == k1)) : 0;
+    const int hp = half == 0 ? h0 : (h1 < 0 ? h0 : h1);
+    const int len = half == 0 ? len0 : len1;
+    const bool active = half == 0 || h1 >= 0;
+    const unsigned k = half == 0 ? k0 : k1;
+    float a0 = 0.f, a1 = 0.f;
+    const int steps = len0 > len1 ? len0 : len1;
+    for (int t = 0; t < steps; ++t) {
+      const int q = min(hp + t, 63);
+      const size_t r = (size_t)(unsigned)__shfl((int)srme, q, 64) * ld;
+      const float w = __shfl(wme, q, 64);   // both cross-lane reads with every lane enabled
+      if (t < len) {
+        if (c < F) a0 = fmaf(w, rows[r + c], a0);
+        if (c + 32 < F) a1 = fmaf(w, rows[r + c + 32], a1);
+      }
+    }
+    if (active && hp + len == 64) {   // the run may continue in the next wave's positions
+      for (long long p = base + 64; p < n && keys[p] == k; ++p) {
+        const unsigned pr = pair_sorted[p];
+        const size_t r = (size_t)src_row[pr] * ld;
+        const float w = pair_w[pr];
+        if (c < F) a0 = fmaf(w, rows[r + c], a0);
+        if (c + 32 < F) a1 = fmaf(w, rows[r + c + 32], a1);
+      }
+    }
+    if (active) {
+      if (c < F) out[(size_t)k * F + c] = a0;
+      if (c + 32 < F) out[(size_t)k * F + c + 32] = a1;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ v, long long n) {
@@ -223,7 +266,7 @@ PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* feat
                                                          0, bits, st));
     }
     pings::prof::Scope ps("sdf_bwd_segsum", st);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((n * 32 + 255) / 256)), dim3(256), 0, st, s.keys_s, s.pair_s, n,
+    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.keys_s, s.pair_s, n,
                        invalid_key, F, IN, s.src_row, s.pair_w, s.gX, dL_dfeatures);
     PINGS_LAUNCH_CHECK();
   }
