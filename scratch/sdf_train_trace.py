@@ -5,7 +5,8 @@ from pings_amd import neural_points as hnp
 from types import SimpleNamespace as NS_
 dev = torch.device('cuda:0')
 npm, dec = bench.sdf_synth_map(1_000_000, dev)
-B = 131072
+import os
+B = int(os.environ.get("SDF_B", "131072"))
 x = bench.sdf_queries(npm, B, dev)
 P_ = [torch.nn.Parameter(t.detach().clone()) for t in (dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias)]
 dec_t = NS_(layers=[NS_(weight=P_[0], bias=P_[1])], lout=NS_(weight=P_[2], bias=P_[3]), sdf_scale=dec.sdf_scale, use_leaky_relu=False)
