@@ -65,6 +65,7 @@ def _run_frames(st, mod, device):
         _eq(m.color_features, st[f + "color_features_after"], f + "color_features_after")
         _eq(m.point_certainties, st[f + "point_certainties_after"], f + "point_certainties_after")
         _eq(m.point_ts_update, st[f + "point_ts_update_after"], f + "point_ts_update_after")
+    return m
 
 
 @pytest.mark.parametrize("name", CASES)
