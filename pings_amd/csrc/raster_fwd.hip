@@ -259,10 +259,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   depth_key[g] = key;
   rect[g] = rc;
   radii[g] = rad;
-  rec[4 * g + 0] = make_float4(mx, my, opac, pz);
-  rec[4 * g + 1] = make_float4(conic_x, conic_y, conic_z, rz);
-  rec[4 * g + 2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], q);
-  rec[4 * g + 3] = make_float4(nx, ny, nz, 0.0f);
+  if (key != CULLED_KEY) {  // nobody reads the record of a culled Gaussian (two thirds of Metric-1's cloud)
+    rec[4 * g + 0] = make_float4(mx, my, opac, pz);
+    rec[4 * g + 1] = make_float4(conic_x, conic_y, conic_z, rz);
+    rec[4 * g + 2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], q);
+    rec[4 * g + 3] = make_float4(nx, ny, nz, 0.0f);
+  }
 }
 
 // Depth ranks are dealt to waves round-robin (lane l of wave w owns rank l*num_waves + w): the
@@ -1150,15 +1152,18 @@ __device__ inline uint32_t wave_reduce_sum_u32(uint32_t v) {
 constexpr int SMALL_RUN = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void per_gaussian_sum_kernel(
-    int P, const uint32_t* __restrict__ gidx_sorted, const uint32_t* __restrict__ offsets_sorted,
-    const uint32_t* __restrict__ tiles_sorted, const T* __restrict__ inst, T* __restrict__ out) {
-  const int r = strided_rank(P);
+    int P, const uint4* __restrict__ rect, const uint32_t* __restrict__ rank_of,
+    const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_sorted,
+    const T* __restrict__ inst, T* __restrict__ out) {
+  // one lane per Gaussian in INDEX order (coalesced output; depth order is random in the index, so long runs are
+  // spread over the waves anyway); the run of a surviving Gaussian is found through its depth rank
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  uint32_t n = 0, base = 0, g = 0;
-  if (r >= 0) {
+  uint32_t n = 0, base = 0;
+  if (g < P && rect[g].w != 0u) {
+    const uint32_t r = rank_of[g];
     n = tiles_sorted[r];
     base = offsets_sorted[r] - n;
-    g = gidx_sorted[r];
   }
   T sum = (T)0;
   if (n <= (uint32_t)SMALL_RUN)
@@ -1186,7 +1191,7 @@ __global__ __launch_bounds__(256) void per_gaussian_sum_kernel(
     }
     if (lane == src) sum = acc;
   }
-  if (r >= 0) out[g] = sum;
+  if (g < P) out[g] = sum;
 }
 
 static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
@@ -1479,11 +1484,11 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
     if (I == 0) {
       PINGS_HIP_CHECK(hipMemsetAsync(per_gaussian, 0, 4 * (size_t)P, st));
     } else if (s->mode == PINGS_RASTER_SURFEL) {
-      hipLaunchKernelGGL(per_gaussian_sum_kernel<float>, grid, block, 0, st, P, gs.gidx_sorted,
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<float>, grid, block, 0, st, P, gs.rect, gs.rank_of,
                          gs.offsets_sorted, gs.tiles_sorted, (const float*)bs.inst_w,
                          reinterpret_cast<float*>(per_gaussian));
     } else {
-      hipLaunchKernelGGL(per_gaussian_sum_kernel<uint32_t>, grid, block, 0, st, P, gs.gidx_sorted,
+      hipLaunchKernelGGL(per_gaussian_sum_kernel<uint32_t>, grid, block, 0, st, P, gs.rect, gs.rank_of,
                          gs.offsets_sorted, gs.tiles_sorted, (const uint32_t*)bs.inst_cnt,
                          reinterpret_cast<uint32_t*>(per_gaussian));
     }
