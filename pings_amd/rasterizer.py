@@ -186,7 +186,7 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     f32 = dict(dtype=torch.float32, device=dev)
     stream = _lib.stream_ptr(dev)
     geom = torch.empty(L.pings_raster_geom_bytes(P, H, W), **u8)
-    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)   # preprocess writes every entry
     # everything that does not depend on the instance count is allocated BEFORE preprocess: that call ends in the
     # frame's one host synchronisation, and the GPU idles from there until the render launches are issued
     image = torch.empty(L.pings_raster_image_bytes(H, W), **u8)
@@ -195,10 +195,10 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
     alpha = torch.empty(1, H, W, **f32)
     if prep.mode == MODE_SURFEL:
         normal = torch.empty(3, H, W, **f32)
-        per_g = torch.zeros(P, **f32)
+        per_g = torch.empty(P, **f32)                       # render writes every entry
     else:
         normal = None
-        per_g = torch.zeros(P, dtype=torch.int32, device=dev)
+        per_g = torch.empty(P, dtype=torch.int32, device=dev)
     out_ptrs = (_lib.ptr(image), _lib.ptr(color), _lib.ptr(normal), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(per_g))
     geom_ptr, ref = _lib.ptr(geom), prep.ref()
     n_inst = C.c_int64(0)
