@@ -534,6 +534,11 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
       const float Tn = T_p * inv_P;                        // transmittance in front of this record
       const float inv_one_m = P_ex * inv_P;                // 1 / (1 - alpha)
       const float w = av * Tn;
+      float S_in;
+      {
+      // gradient accumulation only (alpha / validity were decided above in the forward pass' op order): multiply-adds
+      // may fuse here
+#pragma clang fp contract(fast)
       // s = (upstream gradient) . (features of this record at this pixel)
       float sdot = (c.x * s1.x + c.y * s1.y) + c.z * s1.z;
       v[G_R] = fmaf(s1.x, w, v[G_R]);
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
         v[G_PZ] = fmaf(s1.w, w, v[G_PZ]);
       }
       const float ws = w * sdot;
-      const float S_in = wave_incl_scan_add(ws);           // w s over this and the records behind (in the chunk)
+      S_in = wave_incl_scan_add(ws);                       // w s over this and the records behind (in the chunk)
       const float R_l = R_p + wave_shr1(S_in, 0.f);        // blended behind this record, dotted with the gradient
       // dL/dalpha = T s - (R - coefT) / (1 - alpha)
       float dLda = fmaf(Tn, sdot, (coefT - R_l) * inv_one_m);
@@ -577,6 +582,7 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
       v[G_CONX] += 0.5f * qx * qx * dLp;
       v[G_CONY] += qx * qy * dLp;
       v[G_CONZ] += 0.5f * qy * qy * dLp;
+      }
       if (lane == 63) {                                    // pixel state after the whole chunk
         sPix[pp][0].x = Tn;
         sPix[pp][0].y = R_p + S_in;
