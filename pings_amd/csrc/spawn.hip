@@ -58,61 +58,59 @@ struct GatherArgs {
   uint8_t* free_out;
 };
 
+// One 16-lane group per row (four rows per wave, no grid-stride loop: a wave that walks its rows one after the other
+// pays the sel -> row -> store latency chain once per row).
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
-  const int nwaves = (int)((gridDim.x * (size_t)blockDim.x) >> 6);
-  for (int i = wave; i < a.n; i += nwaves) {
-    const int64_t src = a.sel ? a.sel[i] : (int64_t)i;
-    // small per-point attributes: lanes 0..2 position, 4..7 quaternion, 8..10 colour
-    float pv = 0.f;
-    if (lane < 3) {
-      pv = a.position[src * 3 + lane];
-      a.pos[(size_t)i * 3 + lane] = pv;
-    } else if (lane >= 4 && lane < 8) {
-      pv = a.orientation[src * 4 + (lane - 4)];
-      a.quat[(size_t)i * 4 + (lane - 4)] = pv;
-    } else if (lane >= 8 && lane < 11 && a.color) {
-      a.base[(size_t)i * 3 + (lane - 8)] = a.color[src * 3 + (lane - 8)];
-    } else if (lane == 11 && a.free_mask) {
-      a.free_out[i] = a.free_mask[src];
-    }
-    for (int c = lane; c < a.Fg; c += 64) a.geo_in[(size_t)i * a.ldg + c] = a.geo_feature[src * a.Fg + c];
-    for (int c = lane; c < a.Fc; c += 64) a.col_in[(size_t)i * a.ldc + c] = a.color_feature[src * a.Fc + c];
-    if (a.cam) {
-      const float px = __shfl(pv, 0, 64), py = __shfl(pv, 1, 64), pz = __shfl(pv, 2, 64);
-      Q4 q;
-      q.w = __shfl(pv, 4, 64); q.x = __shfl(pv, 5, 64); q.y = __shfl(pv, 6, 64); q.z = __shfl(pv, 7, 64);
-      float vx = px - a.cam[0], vy = py - a.cam[1], vz = pz - a.cam[2];
-      if (a.xy_only) vz = 0.f;                                  // before the norm (:592-597)
-      const float dist = sqrtf((vx * vx + vy * vy) + vz * vz);
-      vx /= dist; vy /= dist; vz /= dist;
-      if (lane == 0) {
-        if (a.view_dist) a.view_dist[i] = dist;
-        if (a.dist_concat) a.geo_in[(size_t)i * a.ldg + a.Fg] = dist;
-        if (a.view_concat) {
-          float ox, oy, oz;
-          rotate(q, +1.f, vx, vy, vz, ox, oy, oz);             // apply_quaternion_rotation(quat_inverse(q), v)
-          float* d = a.col_in + (size_t)i * a.ldc + a.Fc;
-          d[0] = ox; d[1] = oy; d[2] = oz;
-        }
+  const int lane = threadIdx.x & 15;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (i >= a.n) return;   // whole groups leave together: the width-16 shuffles below stay inside live groups
+  const int64_t src = a.sel ? a.sel[i] : (int64_t)i;
+  // small per-point attributes: lanes 0..2 position, 4..7 quaternion, 8..10 colour
+  float pv = 0.f;
+  if (lane < 3) {
+    pv = a.position[src * 3 + lane];
+    a.pos[(size_t)i * 3 + lane] = pv;
+  } else if (lane >= 4 && lane < 8) {
+    pv = a.orientation[src * 4 + (lane - 4)];
+    a.quat[(size_t)i * 4 + (lane - 4)] = pv;
+  } else if (lane >= 8 && lane < 11 && a.color) {
+    a.base[(size_t)i * 3 + (lane - 8)] = a.color[src * 3 + (lane - 8)];
+  } else if (lane == 11 && a.free_mask) {
+    a.free_out[i] = a.free_mask[src];
+  }
+  for (int c = lane; c < a.Fg; c += 16) a.geo_in[(size_t)i * a.ldg + c] = a.geo_feature[src * a.Fg + c];
+  for (int c = lane; c < a.Fc; c += 16) a.col_in[(size_t)i * a.ldc + c] = a.color_feature[src * a.Fc + c];
+  if (a.cam) {
+    const float px = __shfl(pv, 0, 16), py = __shfl(pv, 1, 16), pz = __shfl(pv, 2, 16);
+    Q4 q;
+    q.w = __shfl(pv, 4, 16); q.x = __shfl(pv, 5, 16); q.y = __shfl(pv, 6, 16); q.z = __shfl(pv, 7, 16);
+    float vx = px - a.cam[0], vy = py - a.cam[1], vz = pz - a.cam[2];
+    if (a.xy_only) vz = 0.f;                                  // before the norm (:592-597)
+    const float dist = sqrtf((vx * vx + vy * vy) + vz * vz);
+    vx /= dist; vy /= dist; vz /= dist;
+    if (lane == 0) {
+      if (a.view_dist) a.view_dist[i] = dist;
+      if (a.dist_concat) a.geo_in[(size_t)i * a.ldg + a.Fg] = dist;
+      if (a.view_concat) {
+        float ox, oy, oz;
+        rotate(q, +1.f, vx, vy, vz, ox, oy, oz);             // apply_quaternion_rotation(quat_inverse(q), v)
+        float* d = a.col_in + (size_t)i * a.ldc + a.Fc;
+        d[0] = ox; d[1] = oy; d[2] = oz;
       }
     }
   }
 }
 
 // Rows `sel` of the (pre-zeroed) map-sized gradient tensors receive the per-view feature gradients; `sel`
-// holds distinct rows (it is the nonzero() of a mask), so this is a plain scatter.
+// holds distinct rows (it is the nonzero() of a mask), so this is a plain scatter.  16 lanes per row.
 __global__ __launch_bounds__(256) void gather_bwd_kernel(int n, const int64_t* __restrict__ sel,
                                                          const float* __restrict__ d_in, int F, int ld,
                                                          float* __restrict__ d_feature) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
-  const int nwaves = (int)((gridDim.x * (size_t)blockDim.x) >> 6);
-  for (int i = wave; i < n; i += nwaves) {
-    const int64_t dst = sel ? sel[i] : (int64_t)i;
-    for (int c = lane; c < F; c += 64) d_feature[dst * F + c] = d_in[(size_t)i * ld + c];
-  }
+  const int lane = threadIdx.x & 15;
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (i >= n) return;
+  const int64_t dst = sel ? sel[i] : (int64_t)i;
+  for (int c = lane; c < F; c += 16) d_feature[dst * F + c] = d_in[(size_t)i * ld + c];
 }
 
 // ------------------------------------------------------------------ per-Gaussian activations
@@ -345,9 +343,9 @@ size_t scan_temp_bytes(int64_t nk) {
   return (b + 255) & ~(size_t)255;
 }
 
-int grid_waves(int n) {  // one wave per row, capped (grid-stride)
-  const int blocks = (int)pings::ceil_div<int64_t>((int64_t)n, 4);
-  return blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+int grid_rows16(int n) {  // one 16-lane group per row, 16 rows per 256-thread workgroup
+  const int blocks = (int)pings::ceil_div<int64_t>((int64_t)n, 16);
+  return blocks < 1 ? 1 : blocks;
 }
 
 }  // namespace
@@ -376,7 +374,7 @@ PINGS_API int pings_spawn_gather(int n, const int64_t* sel, const float* positio
   a.view_dist = view_dist; a.free_out = free_out;
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope sc("spawn_gather", st);
-  gather_kernel<<<grid_waves(n), 256, 0, st>>>(a);
+  gather_kernel<<<grid_rows16(n), 256, 0, st>>>(a);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
@@ -390,12 +388,12 @@ PINGS_API int pings_spawn_gather_backward(int n, const int64_t* sel, const float
   pings::prof::Scope sc("spawn_gather_bwd", st);
   if (dL_dgeo_in) {
     PINGS_ARG_CHECK(dL_dgeo_feature && Fg > 0 && ldg >= Fg, "bad geo gradient arguments");
-    gather_bwd_kernel<<<grid_waves(n), 256, 0, st>>>(n, sel, dL_dgeo_in, Fg, ldg, dL_dgeo_feature);
+    gather_bwd_kernel<<<grid_rows16(n), 256, 0, st>>>(n, sel, dL_dgeo_in, Fg, ldg, dL_dgeo_feature);
     PINGS_LAUNCH_CHECK();
   }
   if (dL_dcol_in) {
     PINGS_ARG_CHECK(dL_dcolor_feature && Fc > 0 && ldc >= Fc, "bad colour gradient arguments");
-    gather_bwd_kernel<<<grid_waves(n), 256, 0, st>>>(n, sel, dL_dcol_in, Fc, ldc, dL_dcolor_feature);
+    gather_bwd_kernel<<<grid_rows16(n), 256, 0, st>>>(n, sel, dL_dcol_in, Fc, ldc, dL_dcolor_feature);
     PINGS_LAUNCH_CHECK();
   }
   return PINGS_OK;
