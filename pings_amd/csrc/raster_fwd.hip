@@ -251,7 +251,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int tiles = (xmax - xmin) * (ymax - ymin);
     if (tiles > 0) {
       key = __float_as_uint(pz);
-      rc = make_uint4(0u, (uint32_t)xmin | ((uint32_t)ymin << 16),
+      // rect.x = 1 iff the footprint can contain a whole tile: every corner of a 15 x 15 pixel square inside the
+      // alpha >= 1/255 ellipse needs a minor semi-axis sqrt(thr lambda_min) >= 7.5 px.  Only such Gaussians can add
+      // to a tile's occlusion budget (tile_min_alpha > 0); the budget pass skips the rectangles of all the others.
+      // Threshold 50 instead of 56.25: slack for the rounding of lambda_min and of tile_min_alpha's own margins.
+      const float lam_min = mid - sqrtf(fmaxf(mid * mid - det, 0.0f));
+      const uint32_t covers = (2.0f * logf(255.0f * opac)) * lam_min >= 50.0f ? 1u : 0u;
+      rc = make_uint4(covers, (uint32_t)xmin | ((uint32_t)ymin << 16),
                       (uint32_t)xmax | ((uint32_t)ymax << 16), (uint32_t)tiles);
       rad = (int)radius;
     }
@@ -541,7 +547,8 @@ __global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
                                                           const uint32_t* __restrict__ nvalid, int num_tiles,
                                                           uint32_t* __restrict__ bucket) {
   const int r = strided_rank(P);
-  const RectLane me = rect_lane(r, gidx_sorted, rect);
+  RectLane me = rect_lane(r, gidx_sorted, rect);
+  if (r >= 0 && rect[me.g].x == 0u) me.n = 0u;   // cannot cover a tile: contributes nothing to any budget
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
   if (me.n != 0u) {
     ra = rec[4 * (size_t)me.g + 0];
