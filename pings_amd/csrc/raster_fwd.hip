@@ -251,12 +251,28 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const int tiles = (xmax - xmin) * (ymax - ymin);
     if (tiles > 0) {
       key = __float_as_uint(pz);
-      // rect.x = 1 iff the footprint can contain a whole tile: every corner of a 15 x 15 pixel square inside the
-      // alpha >= 1/255 ellipse needs a minor semi-axis sqrt(thr lambda_min) >= 7.5 px.  Only such Gaussians can add
-      // to a tile's occlusion budget (tile_min_alpha > 0); the budget pass skips the rectangles of all the others.
-      // Threshold 50 instead of 56.25: slack for the rounding of lambda_min and of tile_min_alpha's own margins.
+      // rect.x: the INNER rectangle of the occlusion-budget pass, as four 8-bit margins inside the tile rectangle
+      // (left, right, top, bottom; margins that meet = empty).  A tile adds to the budget only if all of its pixels
+      // pass the alpha test (tile_min_alpha > 0), i.e. its four corners lie inside the alpha >= 1/255 ellipse, hence
+      // inside that ellipse's bounding box [m - e', m + e'], e' = sqrt(thr cov) with the UNCAPPED thr = 2 ln(255 o)
+      // (the tile rectangle itself is cut at 3 sigma).  Typically the rectangle shrinks by a tile on every side —
+      // half the pairs of a 7 x 7 rectangle.  The bounds are widened by 0.02 tile against rounding; a Gaussian whose
+      // minor semi-axis sqrt(thr lambda_min) is below 7.5 px (threshold 50 = 7.07^2: slack again) cannot hold the
+      // 15 x 15 pixel square of a tile at all.
+      const float thr_u = 2.0f * logf(255.0f * opac);
       const float lam_min = mid - sqrtf(fmaxf(mid * mid - det, 0.0f));
-      const uint32_t covers = (2.0f * logf(255.0f * opac)) * lam_min >= 50.0f ? 1u : 0u;
+      uint32_t inner = 0xFFFFFFFFu;   // empty
+      if (thr_u * lam_min >= 50.0f) {
+        const float exu = sqrtf(thr_u * cxx), eyu = sqrtf(thr_u * cyy);
+        const int ix0 = max(xmin, (int)ceilf((mx - exu) / (float)TILE - 0.02f));
+        const int ix1 = min(xmax, (int)floorf((mx + exu - 15.0f) / (float)TILE + 0.02f) + 1);
+        const int iy0 = max(ymin, (int)ceilf((my - eyu) / (float)TILE - 0.02f));
+        const int iy1 = min(ymax, (int)floorf((my + eyu - 15.0f) / (float)TILE + 0.02f) + 1);
+        if (ix1 > ix0 && iy1 > iy0)
+          inner = (uint32_t)min(ix0 - xmin, 255) | ((uint32_t)min(xmax - ix1, 255) << 8) |
+                  ((uint32_t)min(iy0 - ymin, 255) << 16) | ((uint32_t)min(ymax - iy1, 255) << 24);
+      }
+      const uint32_t covers = inner;
       rc = make_uint4(covers, (uint32_t)xmin | ((uint32_t)ymin << 16),
                       (uint32_t)xmax | ((uint32_t)ymax << 16), (uint32_t)tiles);
       rad = (int)radius;
@@ -548,7 +564,16 @@ __global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
                                                           uint32_t* __restrict__ bucket) {
   const int r = strided_rank(P);
   RectLane me = rect_lane(r, gidx_sorted, rect);
-  if (r >= 0 && rect[me.g].x == 0u) me.n = 0u;   // cannot cover a tile: contributes nothing to any budget
+  if (me.n != 0u) {   // walk only the inner rectangle (preprocess_kernel): tiles outside it cannot be covered
+    const uint4 rc = rect[me.g];
+    const int x0 = me.xmin + (int)(rc.x & 255u), x1 = (int)(rc.z & 0xFFFF) - (int)((rc.x >> 8) & 255u);
+    const int y0 = me.ymin + (int)((rc.x >> 16) & 255u), y1 = (int)(rc.z >> 16) - (int)(rc.x >> 24);
+    if (x1 > x0 && y1 > y0) {
+      me.xmin = x0; me.ymin = y0; me.wdt = x1 - x0; me.n = (uint32_t)((x1 - x0) * (y1 - y0));
+    } else {
+      me.n = 0u;
+    }
+  }
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
   if (me.n != 0u) {
     ra = rec[4 * (size_t)me.g + 0];
