@@ -1,0 +1,32 @@
+"""The bench line contract (task statement: one JSON line with `roofline` and `cpu_baseline`), checked on the newest
+line committed under profiles/ — the file bench.py itself produced on the GPU box."""
+import json
+from pathlib import Path
+
+PROFILES = Path(__file__).resolve().parent.parent / "profiles"
+
+
+def _newest_line():
+    files = sorted(p for p in PROFILES.rglob("*_bench_line.json"))
+    assert files, "no committed bench line"
+    return json.loads(files[-1].read_text()), files[-1]
+
+
+def test_committed_bench_line_keeps_the_contract():
+    d, path = _newest_line()
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (path.name, k)
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    # value is consistent with the step time it was derived from
+    px = d["config"]["width"] * d["config"]["height"]
+    assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
