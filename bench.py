@@ -65,17 +65,24 @@ def camera(W, H, fx, fy, cx, cy, znear, zfar, rank, device):
     return projection(W, H, fx, fy, cx, cy, znear, zfar, T, device)
 
 
-def pmc_traffic(stage):
+def pmc_traffic(stage, workload=None):
     """HBM bytes per launch of `stage`'s kernel from the newest committed rocprofv3 --pmc summary
     (profiles/rNN/*pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes of this very command, FETCH_SIZE
     doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  PMC counters cannot be read from inside the
-    timed process, so the figure is the one measured when the profile was taken; None if there is none."""
+    timed process, so the figure is the one measured when the profile was taken; it is attached only when the
+    summary records the SAME workload (gaussians / width / height / mode) as this run, otherwise None."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
         files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("pmc_traffic.json"))
         if not files:
             return None, None, None
         data = json.load(open(files[-1]))
+        meta = data.get("_workload")
+        if workload is not None and meta is not None and any(meta.get(k) != v for k, v in workload.items()):
+            return None, None, None
+        if workload is not None and meta is None and (workload.get("gaussians"), workload.get("width"),
+                                                      workload.get("height"), workload.get("mode")) != (1_000_000, 1920, 1080, "surfel"):
+            return None, None, None   # round-1 summaries carry no workload record; they were taken on the default
         for name, v in data.items():
             if name.startswith(stage + "_"):
                 return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root)), v.get("valu_insts")
@@ -92,28 +99,87 @@ def parse_prof(txt):
     return out
 
 
-def cpu_baseline_raster(P_sample=16000, W=480, H=272, threads=None):
-    """The oracle (kind "port") timed on a bounded sample of the raster workload: the same cloud
-    statistics, P_sample Gaussians, WxH pixels, fp32, fwd + autograd bwd, on the host cores."""
+def best_threads(fn, candidates=(8, 16, 32, 64, 128)):
+    """Thread count (torch intra-op) at which `fn()` runs fastest on this host, probed once each."""
+    best, best_t = None, float("inf")
+    ncpu = os.cpu_count() or 8
+    for n in candidates:
+        if n > ncpu:
+            break
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = n, dt
+    torch.set_num_threads(best or min(8, ncpu))
+    return torch.get_num_threads()
+
+
+def cpu_baseline_raster(dev, P_sample=16000, W=480, H=272):
+    """The oracle (kind "port") timed on a bounded sample of the raster workload — the same cloud statistics,
+    P_sample Gaussians, WxH pixels, fp32, fwd + autograd bwd, on the host cores — and, since the oracle's outputs
+    are there anyway, used as the CHECKER of the HIP path on the very same inputs: `parity` holds the max relative
+    error of every output and gradient (HIP fp32 vs oracle fp32; normalised by the reference's max-abs)."""
     from oracle import raster_cpu as R
 
-    if threads:
-        torch.set_num_threads(threads)
     fx = fy = 1000.0 * W / 1920.0
+    cx, cy = W / 2 - 0.5, H / 2 - 0.5
     means, col, op, scales, rot = synth_cloud(P_sample, W, H, fx, fy, "cpu", seed=42)
-    cam = R.look_at_camera(W, H, fx, fy, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, dtype=torch.float32)
+    cam = R.look_at_camera(W, H, fx, fy, cx, cy, 0.05, 110.0, dtype=torch.float32)
     s = R.Settings(H, W, cam["tanfovx"], cam["tanfovy"], torch.ones(3), 1.0, cam["viewmatrix"], cam["projmatrix"],
                    cam["projmatrix_raw"], cam["prcppoint"], front_only=True)
-    leaves = [t.clone().requires_grad_(True) for t in (means, col, op, scales, rot)]
+    g = torch.Generator().manual_seed(11)
+    ups = [torch.randn(c, H, W, generator=g) for c in (3, 3, 1, 1)]
+    keys = ("color", "normal", "depth", "alpha")
+
+    def run():
+        leaves = [t.clone().requires_grad_(True) for t in (means, col, op, scales, rot)]
+        th, rh = torch.zeros(3, requires_grad=True), torch.zeros(3, requires_grad=True)
+        out = R.rasterize(*leaves, s, th, rh)
+        loss = sum((out[k] * u).sum() for k, u in zip(keys, ups))
+        return out, torch.autograd.grad(loss, leaves + [th, rh])
+
+    small = lambda: R.rasterize(means[:2000], col[:2000], op[:2000], scales[:2000], rot[:2000], s)
+    threads = best_threads(small)
     t0 = time.time()
-    out = R.rasterize(*leaves, s)
-    loss = out["color"].sum() + out["normal"].sum() + out["depth"].sum() + out["alpha"].sum()
-    torch.autograd.grad(loss, leaves)
+    out, grads = run()
     dt = time.time() - t0
-    return {"value": round(W * H / dt / 1e6, 6), "unit": "Mpix/s", "cores": torch.get_num_threads(),
+    # the HIP path on the same inputs
+    from pings_amd import rasterizer as hr
+    dcam = camera(W, H, fx, fy, cx, cy, 0.05, 110.0, 0, dev)
+    rs = hr.SurfelRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=dcam["tanfovx"], tanfovy=dcam["tanfovy"], bg=torch.ones(3, device=dev),
+        scale_modifier=1.0, viewmatrix=dcam["viewmatrix"], projmatrix=dcam["projmatrix"],
+        projmatrix_raw=dcam["projmatrix_raw"], patch_bbox=torch.tensor([0, 0, H - 1, W - 1], dtype=torch.float32, device=dev),
+        prcppoint=dcam["prcppoint"], sh_degree=0, campos=dcam["campos"], prefiltered=False, debug=False,
+        config=torch.tensor([1, 1, 1, 1, 1], dtype=torch.float32, device=dev))
+    rast = hr.SurfelGaussianRasterizer(rs)
+    hl = [t.to(dev).requires_grad_(True) for t in (means, col, op, scales, rot)]
+    th, rh = torch.zeros(3, device=dev, requires_grad=True), torch.zeros(3, device=dev, requires_grad=True)
+    img, nrm, dep, alp, radii, contrib = rast(means3D=hl[0], means2D=torch.zeros_like(hl[0]), colors_precomp=hl[1],
+                                              opacities=hl[2], scales=hl[3], rotations=hl[4], theta=th, rho=rh)
+    torch.autograd.backward([img, nrm, dep, alp], [u.to(dev) for u in ups])
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))
+
+    parity = {"radii_equal": bool((radii.cpu() == out["radii"]).all())}
+    for k, t in zip(keys, (img, nrm, dep, alp)):
+        parity[k] = float(f"{rel(t, out[k]):.3e}")
+    parity["contributions"] = float(f"{rel(contrib, out['contributions']):.3e}")
+    for name, a, b in zip(("d_means3D", "d_colors", "d_opacities", "d_scales", "d_rotations", "d_theta", "d_rho"),
+                          [t.grad for t in hl] + [th.grad, rh.grad], grads):
+        parity[name] = float(f"{rel(a.reshape(b.shape), b):.3e}")
+    parity["note"] = ("HIP fp32 vs oracle fp32 on identical inputs; the oracle's own fp32-vs-fp64 distance on such "
+                      "scenes is 1e-5..2e-3 per gradient tensor (tests/test_raster.py prints both)")
+    return {"value": round(W * H / dt / 1e6, 6), "unit": "Mpix/s", "cores": threads,
             "kind": "port",
             "sample": f"oracle/raster_cpu.py fp32 fwd+bwd, {P_sample} Gaussians of the same distribution at "
-                      f"{W}x{H} ({dt:.1f} s of CPU work; host has {os.cpu_count()} logical cores)"}
+                      f"{W}x{H} ({dt:.1f} s of CPU work, {threads} torch threads = the fastest of 8..128 on this host; "
+                      f"host has {os.cpu_count()} logical cores)",
+            "parity": parity}
 
 
 # --------------------------------------------------------------------------- SDF (Metric 2)
@@ -121,7 +187,7 @@ SDF_PRIMES = (73856093, 19349669, 83492791)
 
 
 def sdf_synth_map(n_points, device, voxel=0.25, search_alpha=0.8, nn_k=6, feat_dim=32, hidden=64,
-                  buffer_size=int(1e8), seed=42):
+                  buffer_size=int(1e8), seed=42, weighted_first=False):
     """SURVEY.md §8d Metric 2 map, built on the device: neural points on the wavy sheet
     z = 2 sin(0.3x) + cos(0.2y), one per 0.25 m voxel, inserted into the 1e8-slot int64 hash table
     with the reference's rule (later insert wins, model/neural_gaussians.py:243-247,299-308)."""
@@ -167,9 +233,9 @@ def sdf_synth_map(n_points, device, voxel=0.25, search_alpha=0.8, nn_k=6, feat_d
              local_point_orientations=torch.tensor([1.0, 0, 0, 0], device=device).repeat(n, 1),
              global2local=torch.cat([torch.arange(n, device=device), torch.tensor([-1], device=device)]),
              neighbor_dx=dxyz, max_valid_dist2=3 * ((2 + 1) * voxel) ** 2, resolution=voxel, after_pgo=False,
-             temporal_local_map_on=False, nn_k=nn_k, weighted_first=False, geo_feature_dim=feat_dim,
+             temporal_local_map_on=False, nn_k=nn_k, weighted_first=weighted_first, geo_feature_dim=feat_dim,
              color_feature_dim=0, dtype=torch.float32,
-             config=NS(query_nn_k=nn_k, weighted_first=False, layer_norm_on=False))
+             config=NS(query_nn_k=nn_k, weighted_first=weighted_first, layer_norm_on=False))
     npm.point_orientations = npm.local_point_orientations
     decoder = NS(layers=[NS(weight=dec["layers.0.weight"], bias=dec["layers.0.bias"])],
                  lout=NS(weight=dec["lout.weight"], bias=dec["lout.bias"]), sdf_scale=0.55 * 0.05,
@@ -183,79 +249,13 @@ def sdf_queries(npm, B, device, seed=7):
     return (npm.neural_points[sel] + torch.randn(B, 3, generator=g, device=device) * (0.5 * npm.resolution)).contiguous()
 
 
-def bench_sdf(dev, steps, warmup, n_points=1_000_000, batches=(16384, 131072)):
-    """Metric 2: Msamples/s of the fused query (search + gather + IDW + MLP) and of the training-style
-    fwd+bwd (HIP search + autograd through gather/IDW/MLP to features and MLP weights)."""
+def bench_sdf(dev, steps, warmup, n_points=1_000_000):
+    """The 1M-point Metric-2 map: tracker registration step here, query / training rates in `bench_sdf_sweep`."""
     from pings_amd import neural_points as hnp
 
     npm, dec = sdf_synth_map(n_points, dev)
-    out = {"neural_points": int(npm.neural_points.shape[0]), "voxel_m": 0.25, "K": int(npm.neighbor_dx.shape[0]),
-           "nn_k": 6, "feature_dim": 32, "hidden": 64, "buffer_size": int(1e8)}
-    for B in batches:
-        x = sdf_queries(npm, B, dev)
-        for _ in range(warmup):
-            hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sdf, _, cnt, _ = hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
-        torch.cuda.synchronize()
-        t_f = (time.perf_counter() - t0) / steps
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            hnp.sdf_fused(npm, dec, x, need_grad=True, use_only_measured_points=False)
-        torch.cuda.synchronize()
-        t_g = (time.perf_counter() - t0) / steps
-        # training-style fwd+bwd
-        feats = npm.local_geo_features.detach().clone().requires_grad_(True)
-        npm.local_geo_features = feats
-        W = [dec.layers[0].weight.detach().clone().requires_grad_(True), dec.layers[0].bias.detach().clone().requires_grad_(True),
-             dec.lout.weight.detach().clone().requires_grad_(True), dec.lout.bias.detach().clone().requires_grad_(True)]
-
-        def train_step():
-            geo, _, w, c, _ = hnp.query_feature(npm, x, accumulate_stability=False, use_only_measured_points=False)
-            h = torch.relu(torch.nn.functional.linear(geo, W[0], W[1]))
-            s = (torch.nn.functional.linear(h, W[2], W[3]) * dec.sdf_scale * w).sum(1).squeeze(1)
-            loss = s.abs().mean()
-            return torch.autograd.grad(loss, [feats] + W)
-
-        for _ in range(warmup):
-            train_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            train_step()
-        torch.cuda.synchronize()
-        t_t = (time.perf_counter() - t0) / steps
-        # fused training step: pings_sdf_forward + pings_sdf_backward (deterministic scatter), same loss
-        P_ = [torch.nn.Parameter(t.detach().clone()) for t in W]
-        from types import SimpleNamespace as NS_
-        dec_t = NS_(layers=[NS_(weight=P_[0], bias=P_[1])], lout=NS_(weight=P_[2], bias=P_[3]),
-                    sdf_scale=dec.sdf_scale, use_leaky_relu=False)
-        feats_t = npm.geo_features.detach().clone().requires_grad_(True)
-        npm.local_geo_features = feats_t
-
-        def fused_train_step():
-            s_, _ = hnp.sdf_train(npm, dec_t, x, use_only_measured_points=False)
-            return torch.autograd.grad(s_.abs().mean(), [feats_t] + P_)
-
-        for _ in range(warmup):
-            fused_train_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fused_train_step()
-        torch.cuda.synchronize()
-        t_ft = (time.perf_counter() - t0) / steps
-        out[f"B{B}"] = {"fwd_fused_Msamples_s": round(B / t_f / 1e6, 2),
-                        "fwd_bwd_fused_Msamples_s": round(B / t_ft / 1e6, 2),
-                        "fwd_with_grad_x_Msamples_s": round(B / t_g / 1e6, 2),
-                        "fwd_bwd_autograd_Msamples_s": round(B / t_t / 1e6, 2),
-                        "fwd_ms": round(t_f * 1e3, 4),
-                        "hbm_alg_GBs_fwd": round(2428 * B / t_f / 1e9, 1),
-                        "hbm_sector_GBs_fwd": round(10400 * B / t_f / 1e9, 1),
-                        "mean_nn_count": round(cnt.float().mean().item(), 2)}
-        npm.local_geo_features = npm.geo_features
+    out = {"voxel_m": 0.25, "K": int(npm.neighbor_dx.shape[0]), "nn_k": 6, "feature_dim": 32, "hidden": 64,
+           "buffer_size": int(1e8), "algorithmic_bytes_per_sample_fwd": 2428}
     # SURVEY.md 8f.3: one tracker registration iteration = query_source_points (sdf, d sdf/dx, std, mask, certainty:
     # one fused kernel per batch) + implicit_reg (6x6 normal equations kernel + fp64 solve), 131072 source points
     from types import SimpleNamespace as NS_
@@ -443,9 +443,307 @@ def bench_map(dev, frames=6, n_scan=1_000_000, voxel=0.1, with_cpu=True):
     return out
 
 
-def cpu_baseline_sdf(npm, dec, B=131072, reps=8):
-    """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores,
-    same map and queries as the GPU run (tensors copied to the host)."""
+def _timeit(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _prof_run(L, fn, steps):
+    """Per-stage HIP-event times (ms per step) of `steps` calls of fn with every library stage recorded."""
+    L.pings_prof_only(None)
+    L.pings_prof_enable(1)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    L.pings_prof_enable(0)
+    buf = C.create_string_buffer(16384)
+    L.pings_prof_report(buf, len(buf))
+    return {k: v[1] / steps for k, v in parse_prof(buf.value.decode()).items()}
+
+
+def bench_sdf_sweep(dev, steps, warmup, sizes=(200_000, 1_000_000, 5_000_000), with_cpu=True):
+    """Metric 2 at the three map sizes BASELINE.md §3 names (N_np = 2e5 / 1e6 / 5e6, 1e8-slot table, K = 81, k = 6,
+    F = 32, hidden 64) plus the C1 (PIN-SLAM, config/run_pin_slam.yaml) variant: forward and training-step rates at
+    B = 16,384 and 131,072, each forward with an explicit roofline object (algorithmic 2,428 B/sample, SURVEY §8d,
+    against the HBM peak; `traffic` = PMC bytes per launch when a matching profile is committed)."""
+    from pings_amd import neural_points as hnp
+
+    L = _lib_handle()
+    out = {}
+    for n_points in sizes:
+        npm, dec = sdf_synth_map(n_points, dev)
+        leg = {"neural_points": int(npm.neural_points.shape[0])}
+        for B in (16384, 131072):
+            x = sdf_queries(npm, B, dev)
+            fwd = lambda: hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
+            t_wall = _timeit(fwd, steps, warmup)
+            t_k = _prof_run(L, fwd, steps)["sdf_forward"] * 1e-3
+            alg = 2428 * B
+            leg[f"B{B}"] = {"fwd_Msamples_s": round(B / t_wall / 1e6, 2), "fwd_kernel_ms": round(t_k * 1e3, 4),
+                            "roofline": {"kernel": "sdf_forward_kernel", "bound": "hbm",
+                                         "achieved": round(alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
+                                         "traffic": sdf_pmc_traffic(n_points, B)}}
+            leg[f"B{B}"].update(sdf_train_rates(npm, dec, x, steps, warmup))
+        out[f"N{n_points}"] = leg
+        del npm, dec
+        torch.cuda.empty_cache()
+    # C1: voxel 0.4, search_alpha 0.5, F = 8, weighted_first, B = 10,000 (config/run_pin_slam.yaml)
+    npm, dec = sdf_synth_map(200_000, dev, voxel=0.4, search_alpha=0.5, feat_dim=8, weighted_first=True)
+    x = sdf_queries(npm, 10000, dev)
+    fwd = lambda: hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
+    t_wall = _timeit(fwd, steps, warmup)
+    c1 = {"neural_points": int(npm.neural_points.shape[0]), "voxel_m": 0.4, "K": int(npm.neighbor_dx.shape[0]),
+          "feature_dim": 8, "weighted_first": True, "B": 10000, "fwd_Msamples_s": round(10000 / t_wall / 1e6, 2)}
+    c1.update(sdf_train_rates(npm, dec, x, steps, warmup))
+    if with_cpu:
+        c1["cpu_baseline"], _ = cpu_baseline_sdf(npm, dec, B=10000, reps=20, weighted_first=True, label="C1 map")
+    out["C1_pin_slam"] = c1
+    del npm, dec
+    torch.cuda.empty_cache()
+    return out
+
+
+def sdf_pmc_traffic(n_points, B):
+    """HBM bytes per launch of sdf_forward_kernel from the committed PMC summary of this configuration, or None."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("sdf_pmc_traffic.json"))
+        if files:
+            return json.load(open(files[-1])).get(f"N{n_points}_B{B}", {}).get("hbm_bytes_corrected")
+    except Exception:
+        pass
+    return None
+
+
+def sdf_train_rates(npm, dec, x, steps, warmup):
+    """Training-step rates on one map / batch: (a) the fused S(x) with its fused first-order backward, (b) the path an
+    unmodified mapper reaches — `query_feature` + the decoder in torch autograd (mapper.py:848-866), first order —
+    and (c) the same with the Eikonal term through get_gradient(create_graph=True) (mapper.py:874-875, :1448)."""
+    from types import SimpleNamespace as NS_
+
+    from pings_amd import neural_points as hnp
+
+    B = x.shape[0]
+    keep = npm.local_geo_features
+    P_ = [torch.nn.Parameter(t.detach().clone()) for t in (dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias)]
+    dec_t = NS_(layers=[NS_(weight=P_[0], bias=P_[1])], lout=NS_(weight=P_[2], bias=P_[3]), sdf_scale=dec.sdf_scale,
+                use_leaky_relu=False)
+    feats = keep.detach().clone().requires_grad_(True)
+    npm.local_geo_features = feats
+    wf = bool(npm.config.weighted_first)
+
+    def fused():
+        s_, _ = hnp.sdf_train(npm, dec_t, x, use_only_measured_points=False)
+        return torch.autograd.grad(s_.abs().mean(), [feats] + P_)
+
+    def sdf_of(xq):
+        geo, _, w, c, _ = hnp.query_feature(npm, xq, accumulate_stability=False, use_only_measured_points=False)
+        h = torch.relu(torch.nn.functional.linear(geo, P_[0], P_[1]))
+        s_ = torch.nn.functional.linear(h, P_[2], P_[3]).squeeze(-1) * dec.sdf_scale
+        return s_ if wf else (s_ * w.squeeze(-1)).sum(1)
+
+    def dropin():
+        return torch.autograd.grad(sdf_of(x).abs().mean(), [feats] + P_)
+
+    def dropin_eikonal():
+        xq = x.detach().clone().requires_grad_(True)
+        s_ = sdf_of(xq)
+        g = torch.autograd.grad(s_, xq, torch.ones_like(s_), create_graph=True)[0]
+        loss = s_.abs().mean() + 0.5 * ((g.norm(2, dim=-1) - 1.0) ** 2).mean()
+        return torch.autograd.grad(loss, [feats] + P_)
+
+    r = {}
+    try:
+        for name, fn in (("fwd_bwd_fused_Msamples_s", fused), ("fwd_bwd_query_feature_Msamples_s", dropin),
+                         ("fwd_bwd_eikonal_query_feature_Msamples_s", dropin_eikonal)):
+            r[name] = round(B / _timeit(fn, steps, warmup) / 1e6, 2)
+    finally:
+        npm.local_geo_features = keep
+    return r
+
+
+def _lib_handle():
+    from pings_amd import _lib
+
+    L = _lib.lib()
+    L.pings_prof_enable.argtypes = [C.c_int]
+    L.pings_prof_report.argtypes = [C.c_char_p, C.c_size_t]
+    L.pings_prof_only.argtypes = [C.c_char_p]
+    return L
+
+
+def bench_ssim(dev, steps, warmup, W=1920, H=1080):
+    """fused-SSIM (utils/mapper.py:1243) forward + backward at 1080p, 3 channels.  Byte model: forward
+    reads both images (2 x 4 B) and, in training mode, writes the three partial-derivative maps (3 x 4 B) per
+    pixel-channel; backward re-reads the maps and both images (5 x 4 B) and writes the gradient (4 B)."""
+    from pings_amd.ssim import fused_ssim
+
+    L = _lib_handle()
+    g = torch.Generator(device=dev).manual_seed(6)
+    a = torch.rand(1, 3, H, W, generator=g, device=dev).requires_grad_(True)
+    b = (a.detach() + 0.1 * torch.randn(1, 3, H, W, generator=g, device=dev)).clamp(0, 1)
+
+    def step():
+        a.grad = None
+        fused_ssim(a, b).backward()
+
+    t_wall = _timeit(step, steps, warmup)
+    pr = _prof_run(L, step, steps)
+    t_f, t_b = pr["ssim_fwd"] * 1e-3, pr["ssim_bwd"] * 1e-3
+    n = 3 * H * W
+    bf, bb = 20 * n, 24 * n
+    return {"width": W, "height": H, "channels": 3, "fwd_ms": round(t_f * 1e3, 4), "bwd_ms": round(t_b * 1e3, 4),
+            "fwd_bwd_wall_ms": round(t_wall * 1e3, 4), "Mpix_s_fwd_bwd_kernels": round(H * W / (t_f + t_b) / 1e6, 1),
+            "roofline": {"kernel": "ssim_fwd+ssim_bwd", "bound": "hbm", "achieved": round((bf + bb) / (t_f + t_b) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((bf + bb) / (t_f + t_b) / 1e9 / HBM_PEAK_GBS, 4),
+                         "fwd_GBs": round(bf / t_f / 1e9, 1), "bwd_GBs": round(bb / t_b / 1e9, 1),
+                         "algorithmic_bytes": bf + bb, "traffic": None}}
+
+
+def _surfel_rast(hr, dev, W, H, fx, fy):
+    cam = camera(W, H, fx, fy, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, 0, dev)
+    rs = hr.SurfelRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.ones(3, device=dev),
+        scale_modifier=1.0, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
+        projmatrix_raw=cam["projmatrix_raw"], patch_bbox=torch.tensor([0, 0, H - 1, W - 1], dtype=torch.float32, device=dev),
+        prcppoint=cam["prcppoint"], sh_degree=0, campos=cam["campos"], prefiltered=False, debug=False,
+        config=torch.tensor([1, 1, 1, 1, 1], dtype=torch.float32, device=dev))
+    return hr.SurfelGaussianRasterizer(rs)
+
+
+def bench_raster_workload(dev, name, cloud, W, H, fx, steps, warmup):
+    """Rasteriser forward + backward on one more workload shape ('also reported at C2, C3'), same step as
+    the headline: Mpix/s, instance count, longest tile list and the stage times."""
+    from pings_amd import rasterizer as hr
+
+    L = _lib_handle()
+    rast = _surfel_rast(hr, dev, W, H, fx, fx)
+    params = [t.requires_grad_(True) for t in cloud]
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    gg = torch.Generator(device=dev).manual_seed(7)
+    ups = [torch.randn(c, H, W, generator=gg, device=dev) for c in (3, 3, 1, 1)]
+
+    def step():
+        for p_ in params + [theta, rho]:
+            p_.grad = None
+        img, nrm, dep, alp, radii, contrib = rast(means3D=params[0], means2D=torch.zeros_like(params[0]),
+                                                  colors_precomp=params[1], opacities=params[2], scales=params[3],
+                                                  rotations=params[4], theta=theta, rho=rho)
+        torch.autograd.backward([img, nrm, dep, alp], ups)
+        return radii
+
+    radii = step()
+    t = _timeit(step, steps, warmup)
+    pr = _prof_run(L, step, max(2, steps // 4))
+    with torch.no_grad():
+        fs, _, _ = hr._forward(rast._prepared(), *[p_.detach() for p_ in params])
+        _, rg_, _, nc_ = hr.debug_lists(fs)
+        lens = rg_[:, 1] - rg_[:, 0]
+    P = params[0].shape[0]
+    return {"workload": name, "gaussians": P, "width": W, "height": H, "ms_per_step": round(t * 1e3, 4),
+            "Mpix_s": round(W * H / t / 1e6, 1), "instances": int(fs.I), "visible_gaussians": int((radii > 0).sum().item()),
+            "mean_list_len_per_tile": round(float(lens.float().mean()), 1), "longest_list": int(lens.max()),
+            "max_contributors_per_pixel": int(nc_.max()),
+            "kernels_ms": {k: round(v, 4) for k, v in pr.items()}}
+
+
+class _BenchDecoder(torch.nn.Module):
+    """Duck-typed `Decoder` (model/decoder.py:15-98): one hidden level, ReLU, bias."""
+
+    def __init__(self, fin, hidden, out_dim, K, gen, device):
+        super().__init__()
+        self.layers = torch.nn.ModuleList([torch.nn.Linear(fin, hidden)])
+        self.lout = torch.nn.Linear(hidden, out_dim * K)
+        with torch.no_grad():
+            self.layers[0].weight.copy_(torch.randn(hidden, fin, generator=gen) / fin ** 0.5)
+            self.layers[0].bias.copy_(0.1 * torch.randn(hidden, generator=gen))
+            self.lout.weight.copy_(torch.randn(out_dim * K, hidden, generator=gen) / hidden ** 0.5 * 0.5)
+            self.lout.bias.copy_(0.1 * torch.randn(out_dim * K, generator=gen))
+        self.out_k, self.mlp_out_dim, self.use_leaky_relu = K, out_dim * K, False
+        self.to(device)
+
+
+def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8):
+    """One iteration of the Gaussian-mapping loop body as an unmodified mapper reaches it (utils/mapper.py:1126-1295,
+    :1581): `render()` (markVisible -> spawn + the five decoders -> rasterise -> depth2normal -> exposure), the
+    photometric loss block, fused-SSIM, backward to the neural-point features, the decoders, exposure and pose.
+    The rasteriser object is constructed inside render() on every call, as the reference does (:149-201).
+    n_points neural points on a street-like surface, K Gaussians each (F_g 32, F_c 16, hidden 128, pings.py:156-160)."""
+    from pings_amd import _lib
+    from pings_amd.camera import Camera
+    from pings_amd.image_losses import image_losses
+    from pings_amd.renderer import render
+    from pings_amd.ssim import fused_ssim
+
+    L = _lib_handle()
+    sys.path.insert(0, str(ROOT / "tests"))
+    from scenes import street_scene
+
+    g = torch.Generator().manual_seed(8)
+    pos, base_col, _, _, _ = street_scene(n_points, device=dev, seed=2)
+    n = pos.shape[0]
+    quat = torch.tensor([1.0, 0, 0, 0], device=dev).repeat(n, 1)
+    geo = (0.3 * torch.randn(n + 1, 32, generator=g)).to(dev).requires_grad_(True)
+    cfe = (0.3 * torch.randn(n + 1, 16, generator=g)).to(dev).requires_grad_(True)
+    decs = {"gauss_xyz": _BenchDecoder(32, 128, 3, K, g, dev), "gauss_rot": _BenchDecoder(32, 128, 4, K, g, dev),
+            "gauss_scale": _BenchDecoder(32, 128, 3, K, g, dev), "gauss_alpha": _BenchDecoder(32, 128, 1, K, g, dev),
+            "gauss_color": _BenchDecoder(16 + 3, 128, 3, K, g, dev)}
+    data = {"position": pos, "orientation": quat, "color": base_col, "geo_feature": geo, "color_feature": cfe,
+            "resolution": 0.2, "free_mask": torch.zeros(n, dtype=torch.bool, device=dev),
+            "valid_mask": torch.ones(n, dtype=torch.bool, device=dev)}
+    fx = 1000.0 * W / 1920.0
+    cam = Camera(W, H, fx, fx, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, torch.eye(4, dtype=torch.float64), device=dev)
+    bg = torch.ones(3, device=dev)
+    gd = torch.Generator(device=dev).manual_seed(9)
+    gt_rgb = torch.rand(3, H, W, generator=gd, device=dev)
+    gt_depth = 2.0 + 40.0 * torch.rand(1, H, W, generator=gd, device=dev)
+    sky = torch.rand(1, H, W, generator=gd, device=dev) < 0.1
+    leaves = [geo, cfe] + [p for d in decs.values() for p in d.parameters()] + \
+             [cam.exposure_mat, cam.exposure_offset, cam.cam_rot_delta, cam.cam_trans_delta]
+    info = {}
+
+    def step():
+        for p_ in leaves:
+            p_.grad = None
+        pkg = render(cam, None, data, decs, None, bg, view_concat_on=True, learn_color_residual=True, d2n_on=True,
+                     gs_type="gaussian_surfel")
+        il = image_losses(pkg["render"], gt_rgb, pkg["surf_depth"], gt_depth, pkg["rend_alpha"], pkg["rend_normal"],
+                          pkg["surf_normal"], sky, depth_min=0.3, depth_max=80.0, depth_min_accu_alpha=0.4)
+        ssim = fused_ssim(pkg["render"].unsqueeze(0), gt_rgb.unsqueeze(0))
+        loss = 0.8 * il.rgb_l1 + 0.2 * (1.0 - ssim) + 0.5 * il.depth_l1 + 0.05 * il.normal_depth_consist + 0.1 * il.sky
+        loss.backward()
+        info["gaussians"] = int(pkg["gaussian_xyz"].shape[0])
+        info["visible_ratio"] = pkg["visible_neural_point_ratio"]
+
+    step()
+    _lib.sync_counts(reset=True)
+    step()
+    syncs = _lib.sync_counts(reset=True)
+    t = _timeit(step, steps, warmup)
+    pr = _prof_run(L, step, max(2, steps // 4))
+    groups = {"decoders_fwd": ("mlp_fwd",), "decoders_bwd": ("mlp_bwd",), "ssim": ("ssim_fwd", "ssim_bwd"),
+              "image_losses": ("image_losses_fwd", "image_losses_bwd")}
+    return {"width": W, "height": H, "neural_points": n, "gaussians_rasterised": info["gaussians"],
+            "visible_neural_point_ratio": round(float(info["visible_ratio"]), 3), "ms_per_step": round(t * 1e3, 4),
+            "Mpix_s": round(W * H / t / 1e6, 1), "host_syncs_per_render": syncs,
+            "host_syncs_total": int(sum(syncs.values())),
+            "stage_ms": {k: round(v, 4) for k, v in sorted(pr.items(), key=lambda kv: -kv[1])},
+            "stage_ms_sum": round(sum(pr.values()), 4),
+            "grouped_ms": {k: round(sum(pr.get(n_, 0.0) for n_ in v), 4) for k, v in groups.items()}}
+
+
+def cpu_baseline_sdf(npm, dec, B=131072, reps=8, weighted_first=False, label="1M-point map"):
+    """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores, one process,
+    same map and queries as the GPU run (tensors copied to the host); the torch thread count is the fastest of
+    8..128 on this host (the survey container's 8 vCPUs gave 0.26-0.36 Msamples/s)."""
     from oracle import sdf_cpu
 
     c = lambda t: t.detach().cpu().numpy()
@@ -458,20 +756,23 @@ def cpu_baseline_sdf(npm, dec, B=131072, reps=8):
               local_point_orientations=c(npm.point_orientations), local_geo_features=c(npm.geo_features),
               local_point_certainties=c(npm.point_certainties), local_point_ts_update=c(npm.point_ts_create),
               global2local=c(npm.global2local), neighbor_dx=c(npm.neighbor_dx), max_valid_dist2=npm.max_valid_dist2,
-              resolution=npm.resolution, after_pgo=False, temporal_local_map_on=False, nn_k=6, weighted_first=False)
+              resolution=npm.resolution, after_pgo=False, temporal_local_map_on=False, nn_k=6,
+              weighted_first=weighted_first)
     cm = sdf_cpu.NeuralPointMap(st)
     mlp = sdf_cpu.MLP(dec.layers[0].weight.cpu(), dec.layers[0].bias.cpu(), dec.lout.weight.cpu(), dec.lout.bias.cpu(),
                       dec.sdf_scale)
     x = sdf_queries(npm, B, npm.neural_points.device).cpu()
     with torch.no_grad():
         sdf_cpu.mapper_sdf(cm, mlp, x)  # warm-up
+        threads = best_threads(lambda: sdf_cpu.mapper_sdf(cm, mlp, x[:min(B, 32768)]))
         t0 = time.time()
         for _ in range(reps):
             s, _ = sdf_cpu.mapper_sdf(cm, mlp, x)
         dt = (time.time() - t0) / reps
-    return {"value": round(B / dt / 1e6, 4), "unit": "Msamples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/sdf_cpu.py (reference torch op sequence) forward, B={B} queries x {reps} reps on the same "
-                      f"1M-point map ({dt * reps:.1f} s of CPU work; host has {os.cpu_count()} logical cores)"}, s
+    return {"value": round(B / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/sdf_cpu.py (reference torch op sequence) forward, 1 process, B={B} queries x {reps} reps on "
+                      f"the same {label} ({dt * reps:.1f} s of CPU work, {threads} torch threads = the fastest of 8..128; "
+                      f"host has {os.cpu_count()} logical cores)"}, s
 
 
 def main():
@@ -548,8 +849,36 @@ def main():
     gN = torch.randn(3, H, W, generator=gg, device=dev)
     gD = torch.randn(1, H, W, generator=gg, device=dev)
     gA = torch.randn(1, H, W, generator=gg, device=dev)
-    flat_grad = torch.empty(P * 14, device=dev) if world > 1 else None
     stats = {}
+    # N > 1: the exchange step of a multi-view iteration (mapper.py:1581-1584): mean over ranks of the
+    # gradients of local_geo_features [N_np+1, 32] + local_color_features [N_np+1, 16] (ONE [N_np+1, 48] table, row-
+    # sparse: only the neural points this rank's view sees) and of the six decoder MLPs (flat bucket, async all-reduce
+    # overlapped with the table exchange).  The timed step stays the rasteriser step of the headline metric; the
+    # feature-gradient rows are the per-neural-point sums of the Gaussian gradients (8 Gaussians per point) — the
+    # spawn / decoder adjoint that produces the real values is measured in `render_step`, not here.
+    ex = None
+    if world > 1:
+        n_np = P // 8
+        g_tab = torch.zeros(n_np + 1, 48, device=dev)
+        mlp_shapes = [(128, 32), (128,), (24, 128), (24,), (128, 32), (128,), (32, 128), (32,), (128, 32), (128,),
+                      (24, 128), (24,), (128, 32), (128,), (8, 128), (8,), (128, 19), (128,), (24, 128), (24,),
+                      (64, 35), (64,), (1, 64), (1,)]
+        mlp_params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in mlp_shapes]
+        b_mlp = pdist.GradBucket(mlp_params, overlap=False)
+        ex = pdist.RowSparseExchange()
+
+    def exchange(radii):
+        b_mlp.zero()
+        g14 = torch.cat([params[0].grad, params[1].grad, params[2].grad, params[3].grad, params[4].grad], 1)
+        g_np = g14[:n_np * 8].view(n_np, 8, 14).sum(1)
+        b_mlp.flat.add_(g_np.mean())
+        b_mlp._launch()                                     # decoder bucket travels while the table is compacted
+        seen = (radii[:n_np * 8].view(n_np, 8) > 0).any(1)
+        rows = torch.nonzero(seen).flatten()                # the count sizes the gather (spawn reads it back anyway)
+        g_tab.zero_()
+        g_tab[rows] = torch.cat([g_np, g_np, g_np, g_np[:, :6]], 1)[rows]
+        ex.reduce_(g_tab, rows)
+        b_mlp.finish()
 
     def step():
         for p_ in params + [theta, rho]:
@@ -564,8 +893,7 @@ def main():
             img, radii, dep, alp, nt = out
             torch.autograd.backward([img, dep, alp], [gC, gD, gA])
         if world > 1:
-            # multi-view step: mean of the per-view parameter gradients, one bucket over RCCL
-            pdist.allreduce_grads(params, bucket=flat_grad)
+            exchange(radii)
         stats["visible"] = radii
         return out
 
@@ -640,7 +968,7 @@ def main():
             "gaussian_bwd": 56 * P + 64 * P,
         }
         achieved = alg[dom] / (per[dom] * 1e-3) / 1e9
-        traffic, traffic_src, valu_insts = pmc_traffic(dom)
+        traffic, traffic_src, valu_insts = pmc_traffic(dom, dict(gaussians=P, width=W, height=H, mode=args.mode))
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -658,7 +986,7 @@ def main():
                        "alg_GBs": round(alg[k] / (per[k] * 1e-3) / 1e9, 1) if k in alg else None} for k in per}
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline_raster()
+            cpu = cpu_baseline_raster(dev)
         sdf = None
         if not args.no_sdf:
             for p_ in params:
@@ -670,23 +998,56 @@ def main():
                 sdf["cpu_baseline"], _ = cpu_baseline_sdf(npm, dec)
             del npm, dec
             torch.cuda.empty_cache()
-        decoder = bench_decoder(dev, max(args.steps, 5), max(args.warmup, 2)) if not args.no_sdf else None
-        map_maint = bench_map(dev, with_cpu=not args.no_cpu_baseline) if not args.no_sdf else None
-        img_losses = bench_image_losses(dev, max(args.steps, 5), max(args.warmup, 2), with_cpu=not args.no_cpu_baseline) if not args.no_sdf else None
+        ks, kw = max(args.steps, 5), max(args.warmup, 2)
+        extras = {}
+        if not args.no_sdf:
+            sys.path.insert(0, str(ROOT / "tests"))
+            from scenes import room_scene, street_scene
+
+            def leg(name, fn):
+                # an extra leg must never take the headline line down with it: its failure is reported in place
+                try:
+                    extras[name] = fn()
+                except Exception as e:  # noqa: BLE001
+                    extras[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+
+            try:
+                sdf.update(bench_sdf_sweep(dev, ks, kw, with_cpu=not args.no_cpu_baseline))
+            except Exception as e:  # noqa: BLE001
+                sdf["sweep_error"] = f"{type(e).__name__}: {e}"
+            torch.cuda.empty_cache()
+            leg("ssim", lambda: bench_ssim(dev, ks, kw))
+            leg("raster_c2", lambda: bench_raster_workload(dev, "C2 Replica-like room, 200k surfels, 640x480",
+                                                           room_scene(200_000, device=dev, seed=1), 640, 480, 600.0, ks, kw))
+            leg("raster_c3", lambda: bench_raster_workload(dev, "C3 KITTI-like street, 1M surfels, 1392x512",
+                                                           street_scene(1_000_000, device=dev, seed=1), 1392, 512, 720.0, ks, kw))
+            leg("raster_c3_cloud", lambda: bench_raster_workload(
+                dev, "SURVEY 8d cloud at the C3 shape, 1M Gaussians, 1392x512",
+                synth_cloud(1_000_000, 1392, 512, 725.0, 725.0, dev, seed=42), 1392, 512, 725.0, ks, kw))
+            leg("render_step", lambda: bench_render_step(dev, ks, kw))
+            leg("decoder", lambda: bench_decoder(dev, ks, kw))
+            leg("map_maintenance", lambda: bench_map(dev, with_cpu=not args.no_cpu_baseline))
+            leg("image_losses", lambda: bench_image_losses(dev, ks, kw, with_cpu=not args.no_cpu_baseline))
+        decoder, map_maint, img_losses = extras.pop("decoder", None), extras.pop("map_maintenance", None), \
+            extras.pop("image_losses", None)
         line = {
             "metric": "raster fwd+bwd Mpix/s @1M Gaussians 1080p",
             "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.mode} rasteriser fwd+bwd, {P} Gaussians, {W}x{H}, one view per GPU"
-                                   + (", grad all-reduce (RCCL) of 14 floats/Gaussian" if world > 1 else ""),
+                                   + (", then the multi-view exchange of SURVEY 8e over RCCL: row-sparse all-gather of the "
+                                      "visible neural points' feature-gradient rows [P/8+1, 48] + all-reduce of the six "
+                                      "decoder MLPs" if world > 1 else ""),
+                       "exchange": (ex.last if ex is not None else None),
                        "gaussians": P, "width": W, "height": H, "instances": int(I), "instances_blended": I_proc,
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "sdf": sdf, "decoder": decoder,
-            "map_maintenance": map_maint, "image_losses": img_losses,
+            "map_maintenance": map_maint, "image_losses": img_losses, **extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

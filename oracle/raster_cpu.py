@@ -68,6 +68,8 @@ class Settings:
     prcppoint: torch.Tensor = None       # [2] = (cx/W, cy/H) (cameras.py:61); None -> centre
     front_only: bool = True              # config[4] (gaussian_renderer/__init__.py:142)
     mode: str = "surfel"                 # "surfel" | "3dgs"
+    rect: str = "ellipse"                # tile rectangle: "ellipse" (default, DESIGN §3 assumption 1) | "3sigma" (published 3DGS square)
+    mark_frustum: bool = True            # markVisible: depth AND |ndc| <= 1.3 (assumption 2) | False: depth only
 
 
 def mark_visible(positions: torch.Tensor, s: Settings) -> torch.Tensor:
@@ -85,6 +87,8 @@ def mark_visible(positions: torch.Tensor, s: Settings) -> torch.Tensor:
     hw = ((P[0, 3] * px + P[1, 3] * py) + P[2, 3] * pz) + P[3, 3]
     pw = 1.0 / (hw + 1e-7)
     nx, ny = hx * pw, hy * pw
+    if not getattr(s, "mark_frustum", True):
+        return pz > NEAR_Z
     return (pz > NEAR_Z) & (nx >= -1.3) & (nx <= 1.3) & (ny >= -1.3) & (ny <= 1.3)
 
 
@@ -177,14 +181,24 @@ def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None, op
             k2 = torch.clamp(2.0 * torch.log(255.0 * opacities.reshape(-1).detach()), max=9.0)
         def _tile(v, hi):
             return torch.clamp(torch.floor(v / TILE), 0, hi).to(torch.int64)
-        safe = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius) & (k2 > 0)
+        sq = getattr(s, "rect", "ellipse") == "3sigma"
+        safe = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius)
+        if not sq:
+            safe = safe & (k2 > 0)
         k2s = torch.where(safe, k2, torch.zeros_like(k2))
         mxs = torch.where(safe, mx, torch.zeros_like(mx))
         mys = torch.where(safe, my, torch.zeros_like(my))
-        ex = torch.sqrt(k2s * torch.where(safe, cxx, torch.zeros_like(cxx)))
-        ey = torch.sqrt(k2s * torch.where(safe, cyy, torch.zeros_like(cyy)))
-        xmin, xmax = _tile(mxs - ex, gx), _tile((mxs + ex) + TILE, gx)
-        ymin, ymax = _tile(mys - ey, gy), _tile((mys + ey) + TILE, gy)
+        if sq:
+            # the published 3DGS getRect(): square of half-width ceil(3 sqrt(lambda_max)), upper bound
+            # (m + r + TILE - 1) / TILE.  Selectable so that the deviation of the default stays measurable.
+            ex = ey = torch.where(safe, radius, torch.zeros_like(radius)).detach()
+            up = TILE - 1
+        else:
+            ex = torch.sqrt(k2s * torch.where(safe, cxx, torch.zeros_like(cxx)))
+            ey = torch.sqrt(k2s * torch.where(safe, cyy, torch.zeros_like(cyy)))
+            up = TILE
+        xmin, xmax = _tile(mxs - ex, gx), _tile((mxs + ex) + up, gx)
+        ymin, ymax = _tile(mys - ey, gy), _tile((mys + ey) + up, gy)
         tiles = (xmax - xmin) * (ymax - ymin)
         valid = safe & (tiles > 0)
 

@@ -77,3 +77,41 @@ def ptr(t: torch.Tensor | None):
 
 def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# ---------------------------------------------------------------- host round trips
+# Every place where the host waits for a device value (a D2H read-back) calls note_sync(), so that bench.py can report
+# `host_syncs_per_render` and tests can pin the count.  The reference's `render` has three of its own
+# (gaussian_renderer/__init__.py:219 `.item()`, :305 NaN assert, and the boolean-mask compaction in spawn :730-737).
+SYNC_LOG: dict[str, int] = {}
+
+
+def note_sync(what: str) -> None:
+    SYNC_LOG[what] = SYNC_LOG.get(what, 0) + 1
+
+
+def sync_counts(reset: bool = False) -> dict[str, int]:
+    out = dict(SYNC_LOG)
+    if reset:
+        SYNC_LOG.clear()
+    return out
+
+
+def host_values(t: torch.Tensor) -> list:
+    """Values of a small settings tensor on the host.  A tensor built from host numbers carries them as
+    `_pings_host` (`with_host_values`); otherwise one D2H copy is made and remembered on the tensor object, so a
+    persistent camera tensor pays it once, not once per frame."""
+    hv = getattr(t, "_pings_host", None)
+    if hv is None:
+        note_sync("settings_tensor_readback")
+        hv = t.detach().to("cpu", torch.float32).tolist()
+        try:
+            t._pings_host = hv
+        except Exception:
+            pass
+    return hv
+
+
+def with_host_values(t: torch.Tensor, values) -> torch.Tensor:
+    t._pings_host = [float(v) for v in values]
+    return t

@@ -35,6 +35,7 @@ namespace raster {
 struct KParams {
   int P, W, H, gx, gy;
   int front_only;
+  int rect_3sigma;   // PINGS_RASTER_RECT=3sigma: the published 3DGS tile square (A/B: measures what the ellipse box drops)
   float fx, fy, limx, limy, scale_mod;
   const float* view;
   const float* proj_raw;
@@ -136,7 +137,7 @@ __device__ inline void to_camera(const float* __restrict__ V, float x, float y, 
 __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restrict__ pos, int N,
                                                             const float* __restrict__ V,
                                                             const float* __restrict__ Pm,
-                                                            uint8_t* __restrict__ present) {
+                                                            uint8_t* __restrict__ present, int depth_only) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float px, py, pz;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(const float* __restri
   const float hw = ((Pm[3] * px + Pm[7] * py) + Pm[11] * pz) + Pm[15];
   const float pw = 1.0f / (hw + 1e-7f);
   const float nx = hx * pw, ny = hy * pw;
-  present[i] = (pz > NEAR_Z) && (nx >= -1.3f) && (nx <= 1.3f) && (ny >= -1.3f) && (ny <= 1.3f);
+  present[i] = (pz > NEAR_Z) && (depth_only || ((nx >= -1.3f) && (nx <= 1.3f) && (ny >= -1.3f) && (ny <= 1.3f)));
 }
 
 template <int MODE>
@@ -240,14 +241,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   // tile rectangle: bounding box of the footprint ellipse, cut at 3 sigma and at alpha = 1/255
   const float opac = opacities[g];
   const float k2 = fminf(2.0f * logf(255.0f * opac), 9.0f);
-  ok = ok && (k2 > 0.0f);
+  ok = ok && (k2 > 0.0f || p.rect_3sigma);
   if (ok) {
-    const float ex = sqrtf(k2 * cxx), ey = sqrtf(k2 * cyy);
+    // default: bounding box of the ellipse; rect_3sigma: the square of half-width ceil(3 sqrt(lambda_max)) of the
+    // published 3DGS getRect(), upper bound (m + r + TILE - 1) / TILE
+    const float ex = p.rect_3sigma ? radius : sqrtf(k2 * cxx), ey = p.rect_3sigma ? radius : sqrtf(k2 * cyy);
+    const float up = p.rect_3sigma ? (float)(TILE - 1) : (float)TILE;
     const float fgx = (float)p.gx, fgy = (float)p.gy;
     const int xmin = (int)fminf(fmaxf(floorf((mx - ex) / (float)TILE), 0.0f), fgx);
-    const int xmax = (int)fminf(fmaxf(floorf(((mx + ex) + (float)TILE) / (float)TILE), 0.0f), fgx);
+    const int xmax = (int)fminf(fmaxf(floorf(((mx + ex) + up) / (float)TILE), 0.0f), fgx);
     const int ymin = (int)fminf(fmaxf(floorf((my - ey) / (float)TILE), 0.0f), fgy);
-    const int ymax = (int)fminf(fmaxf(floorf(((my + ey) + (float)TILE) / (float)TILE), 0.0f), fgy);
+    const int ymax = (int)fminf(fmaxf(floorf(((my + ey) + up) / (float)TILE), 0.0f), fgy);
     const int tiles = (xmax - xmin) * (ymax - ymin);
     if (tiles > 0) {
       key = __float_as_uint(pz);
@@ -1239,6 +1243,8 @@ static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   kp.gx = ceil_div(kp.W, TILE);
   kp.gy = ceil_div(kp.H, TILE);
   kp.front_only = s->front_only;
+  kp.rect_3sigma = 0;
+  if (const char* e = getenv("PINGS_RASTER_RECT")) kp.rect_3sigma = e[0] == '3';
   kp.fx = (float)((double)kp.W / (2.0 * s->tanfovx));
   kp.fy = (float)((double)kp.H / (2.0 * s->tanfovy));
   kp.limx = (float)(1.3 * s->tanfovx);
@@ -1268,9 +1274,12 @@ PINGS_API int pings_raster_mark_visible(const float* positions, int N,
   PINGS_ARG_CHECK(s && s->viewmatrix && s->projmatrix_raw, "null settings / matrices");
   if (N == 0) return PINGS_OK;
   PINGS_ARG_CHECK(N > 0 && positions && present, "null pointer");
+  // PINGS_MARK_VISIBLE=depth: the variant in which upstream's frustum test stays commented out (assumption 2)
+  int depth_only = 0;
+  if (const char* e = getenv("PINGS_MARK_VISIBLE")) depth_only = e[0] == 'd';
   hipLaunchKernelGGL(mark_visible_kernel, dim3(pings::ceil_div(N, 256)), dim3(256), 0,
                      pings::as_stream(stream), positions, N, s->viewmatrix, s->projmatrix_raw,
-                     present);
+                     present, depth_only);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

@@ -143,6 +143,10 @@ def update(m, points, colors=None, normals=None, sensor_position=None, sensor_or
         _lib.ptr(_u8(bufs["valid_color_mask"])), _lib.ptr(scratch), _lib.ptr(upd), C.byref(n_new),
         _lib.stream_ptr(dev))
     _lib.check(st, "pings_map_update")
+    # the kernels wrote buffer_pt_index through its raw pointer: torch's version counter did not move, so the
+    # query path's compact mirror (neural_points._compact_table) is told explicitly that the table changed
+    m._pings_table_gen = getattr(m, "_pings_table_gen", 0) + 1
+    m.__dict__.pop("_pings_compact", None)
     n_new = int(n_new.value)
     n = n_old + n_new
     for name, buf in bufs.items():

@@ -86,10 +86,12 @@ USE_COMPACT_TABLE = True  # set False to read the reference's dense table direct
 
 
 def _compact_table(npm):
-    """Cache-resident mirror of `buffer_pt_index`, rebuilt whenever the dense tensor changes
-    (identity + in-place version counter)."""
+    """Cache-resident mirror of `buffer_pt_index`, rebuilt whenever the dense tensor changes: identity, torch's
+    in-place version counter (torch-side writes), the explicit generation `neural_map.update` bumps after the HIP
+    insert kernel wrote the table through its raw pointer (which torch's counter cannot see), and the point count."""
     table = npm.buffer_pt_index
-    key = (table.data_ptr(), table._version, table.shape[0])
+    key = (table.data_ptr(), table._version, table.shape[0], getattr(npm, "_pings_table_gen", 0),
+           int(npm.neural_points.shape[0]))
     cache = getattr(npm, "_pings_compact", None)
     if cache is not None and cache[0] == key:
         return cache[1]

@@ -97,9 +97,10 @@ class _Prepared:
             cfg = rs.config
             # config = [surface, normalize_depth, perpix_depth, default, front_only]
             # (gaussian_renderer/__init__.py:137-142).  The reference always passes 1,1,1,1,f;
-            # only that combination is implemented.  Reading the flags costs one small D2H
-            # copy per settings object, so cache it on the tensor's values lazily.
-            cfg_host = cfg.detach().to("cpu", torch.float32).tolist()
+            # only that combination is implemented.  `renderer.render` builds the tensor from host
+            # values and hands them along (`_lib.with_host_values`), so no D2H copy is made there;
+            # a tensor from elsewhere costs one read-back, remembered on the tensor object.
+            cfg_host = _lib.host_values(cfg)
             if len(cfg_host) != 5 or any(v != 1.0 for v in cfg_host[:4]):
                 raise NotImplementedError(
                     f"surfel config {cfg_host}: only surface/normalize_depth/perpix_depth/default = 1 "
@@ -107,7 +108,7 @@ class _Prepared:
             front_only = int(cfg_host[4] != 0.0)
             pb = rs.patch_bbox
             if pb is not None:
-                pbh = pb.detach().to("cpu", torch.float32).tolist()
+                pbh = _lib.host_values(pb)
                 if pbh != [0.0, 0.0, float(self.H - 1), float(self.W - 1)]:
                     raise NotImplementedError(
                         f"patch_bbox {pbh}: only the full-image patch (cameras.py:201-205) is implemented")
@@ -208,6 +209,7 @@ def _forward(prep: _Prepared, means3D, colors, opacities, scales, rotations):
                                    geom_ptr, _lib.ptr(radii), C.byref(n_inst), C.byref(fclass), stream)
     if st:
         _lib.check(st, "pings_raster_preprocess")
+    _lib.note_sync("raster_instance_count")     # pings_raster_preprocess ends in the frame's one read-back
     I = n_inst.value
     binning = torch.empty(L.pings_raster_binning_bytes(I, H, W), **u8)
     st = L.pings_raster_render(ref, P, I, geom_ptr, _lib.ptr(binning), out_ptrs[0], out_ptrs[1], out_ptrs[2],

@@ -79,6 +79,7 @@ def spawn_gaussians(neural_points_data: Dict,
     elif valid is not None:
         mask = valid
     if mask is not None:
+        _lib.note_sync("spawn_mask_nonzero")    # reference: boolean-mask indexing at :563-569
         sel = torch.nonzero(mask).view(-1)      # features[cat(sel, -1)][:-1] == features[sel]  (:563-569,600)
         n = int(sel.shape[0])
     else:
@@ -144,10 +145,15 @@ def _settings(viewpoint_camera, gs_type, height, width, tanfovx, tanfovy, bg_col
                   projmatrix_raw=viewpoint_camera.projection_matrix, sh_degree=0,
                   campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     if gs_type == "gaussian_surfel":
-        cfg = torch.tensor([True, True, True, True, front_only_on], dtype=torch.float32, device=device)  # :137-142
+        # both tensors are built from host numbers (:137-142, cameras.py:201-205); the numbers ride along so that the
+        # rasteriser does not have to read them back from the device every frame
+        flags = [True, True, True, True, bool(front_only_on)]
+        cfg = _lib.with_host_values(torch.tensor(flags, dtype=torch.float32, device=device), flags)
+        pb = viewpoint_camera.full_patch(down_rate)         # == [0, 0, height - 1, width - 1] by its definition
+        if getattr(pb, "_pings_host", None) is None:
+            _lib.with_host_values(pb, [0, 0, height - 1, width - 1])
         return _rast.SurfelGaussianRasterizer(_rast.SurfelRasterizationSettings(
-            patch_bbox=viewpoint_camera.full_patch(down_rate), prcppoint=viewpoint_camera.prcppoint, config=cfg,
-            **common))
+            patch_bbox=pb, prcppoint=viewpoint_camera.prcppoint, config=cfg, **common))
     return _rast.GS3DGaussianRasterizer(_rast.GS3DRasterizationSettings(**common))
 
 
@@ -209,6 +215,7 @@ def render(viewpoint_camera,
         return None                     # :264-265
     visible = rasterizer.markVisible(neural_points_data["position"])
     n_all = visible.shape[0]
+    _lib.note_sync("render_visible_count")                  # reference: :219
     n_vis = int(torch.sum(visible).item())
     if n_vis == 0:
         if verbose:
@@ -250,7 +257,8 @@ def render(viewpoint_camera,
         screenspace_points.retain_grad()
     except Exception:
         pass
-    assert not bool(torch.isnan(rotations).any()), "NaN in rotation"       # :305-306
+    _lib.note_sync("render_nan_assert")                     # reference: :305-306
+    assert not bool(torch.isnan(rotations).any()), "NaN in rotation"
 
     out = rasterizer(means3D=means3D, means2D=screenspace_points, colors_precomp=colors, opacities=opacity,
                      scales=scales, rotations=rotations, theta=viewpoint_camera.cam_rot_delta,

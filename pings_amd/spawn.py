@@ -150,6 +150,7 @@ class _Activate(torch.autograd.Function):
             st = L.pings_spawn_plan(C.byref(p), _lib.ptr(raws[3]), _lib.ptr(raws[2]), _lib.ptr(dist_ratio),
                                     _lib.ptr(scratch), _lib.ptr(dest), _lib.ptr(cnt), _lib.stream_ptr(dev))
             _lib.check(st, "pings_spawn_plan")
+            _lib.note_sync("spawn_kept_count")   # reference: alpha > 0 boolean indexing at :730-737
             count = int(cnt.item())  # the output shapes depend on it (as the reference's boolean indexing does)
         sdim = 3 if p.surfel else p.scale_dim
         xyz, scale, rot = torch.empty(count, 3, **f32), torch.empty(count, sdim, **f32), torch.empty(count, 4, **f32)

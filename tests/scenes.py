@@ -74,3 +74,59 @@ def hip_settings(sc, mode="surfel", front_only=True, scale_modifier=1.0, device=
         scale_modifier=scale_modifier, viewmatrix=f(cam["viewmatrix"]), projmatrix=f(cam["projmatrix"]),
         projmatrix_raw=f(cam["projmatrix_raw"]), sh_degree=0, campos=f(cam["campos"]), prefiltered=False,
         debug=False)
+
+
+# ------------------------------------------------------------------ surface-like scenes at BASELINE.json's shapes
+def _surfels_on(parts, P, gen, device, smin, smax, omin):
+    """Surfels lying on planar patches: `parts` = list of (count, point sampler, normal)."""
+    r = lambda *s: torch.rand(*s, generator=gen, device=device)
+    means = torch.cat([f(n, r) for n, f, _ in parts]).contiguous()
+    nrm = torch.cat([torch.tensor(nv, dtype=torch.float32, device=device).expand(n, 3) for n, _, nv in parts])
+    z = torch.tensor([0.0, 0.0, 1.0], device=device).expand_as(nrm)
+    v = torch.linalg.cross(z, nrm)
+    c = (z * nrm).sum(1, keepdim=True)
+    q = torch.cat([1 + c, v], 1)                       # quaternion turning the z axis onto the normal
+    q[q.norm(dim=1) < 1e-6] = torch.tensor([0.0, 1.0, 0.0, 0.0], device=device)
+    rot = torch.nn.functional.normalize(q, dim=1).contiguous()
+    scales = torch.exp(math.log(smin) + (math.log(smax) - math.log(smin)) * r(P, 3))
+    scales[:, 2] = 1e-7
+    return means, r(P, 3), omin + (1 - omin) * r(P, 1), scales.contiguous(), rot
+
+
+def street_scene(P, device="cuda", seed=0):
+    """KITTI-like view (BASELINE.json config C3): ground plane, two facades and a far wall, surfels on the surfaces,
+    camera at the origin looking down +z (y down).  Tile lists are long and uneven (the horizon), nothing saturates
+    early — the opposite regime of the SURVEY §8d Metric-1 cloud."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = P // 4
+    F = lambda v, k: torch.full((k,), v, device=device)
+    parts = [
+        (n, lambda k, r: torch.stack([(r(k) - 0.5) * 20, F(1.6, k), 2 + 58 * r(k) ** 1.5], 1), [0.0, -1.0, 0.0]),
+        (n, lambda k, r: torch.stack([F(-8.0, k), 1.6 - 6 * r(k), 2 + 58 * r(k) ** 1.5], 1), [1.0, 0.0, 0.0]),
+        (n, lambda k, r: torch.stack([F(8.0, k), 1.6 - 6 * r(k), 2 + 58 * r(k) ** 1.5], 1), [-1.0, 0.0, 0.0]),
+        (P - 3 * n, lambda k, r: torch.stack([(r(k) - 0.5) * 16, 1.6 - 6 * r(k), F(60.0, k)], 1), [0.0, 0.0, -1.0]),
+    ]
+    return _surfels_on(parts, P, g, device, 0.03, 0.25, 0.3)
+
+
+def room_scene(P, device="cuda", seed=0):
+    """Replica-like indoor view (config C2): a 6 x 3 x 8 m room seen from inside (floor, ceiling, three walls)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = P // 5
+    F = lambda v, k: torch.full((k,), v, device=device)
+    parts = [
+        (n, lambda k, r: torch.stack([(r(k) - 0.5) * 6, F(1.4, k), 0.4 + 6.6 * r(k)], 1), [0.0, -1.0, 0.0]),
+        (n, lambda k, r: torch.stack([(r(k) - 0.5) * 6, F(-1.6, k), 0.4 + 6.6 * r(k)], 1), [0.0, 1.0, 0.0]),
+        (n, lambda k, r: torch.stack([F(-3.0, k), 1.4 - 3 * r(k), 0.4 + 6.6 * r(k)], 1), [1.0, 0.0, 0.0]),
+        (n, lambda k, r: torch.stack([F(3.0, k), 1.4 - 3 * r(k), 0.4 + 6.6 * r(k)], 1), [-1.0, 0.0, 0.0]),
+        (P - 4 * n, lambda k, r: torch.stack([(r(k) - 0.5) * 6, 1.4 - 3 * r(k), F(7.0, k)], 1), [0.0, 0.0, -1.0]),
+    ]
+    return _surfels_on(parts, P, g, device, 0.01, 0.06, 0.3)
+
+
+def scene_as_dict(means, col, op, scales, rot, W, H, fx, T_cw=None):
+    """Wrap device tensors of a surface scene into the dict `oracle_settings` / `hip_settings` take (fp64, CPU)."""
+    cam = R.look_at_camera(W, H, fx, fx, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, T_cw=T_cw, dtype=torch.float64)
+    d = lambda t: t.detach().double().cpu()
+    return dict(means=d(means), scales=d(scales), rot=d(rot), op=d(op), col=d(col),
+                bg=torch.tensor([1.0, 1.0, 1.0], dtype=torch.float64), cam=cam, W=W, H=H)

@@ -75,3 +75,99 @@ def test_single_process_is_a_noop():
     assert (p.grad == 2.0).all() and pdist.world() == 1 and pdist.views_for_rank(4) == [0, 1, 2, 3]
     t = torch.arange(5.0)
     assert pdist.allgather_concat(t) is t
+
+
+# ------------------------------------------------------------------ buckets, overlap hooks, row-sparse exchange
+def _make_model(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.nn.Parameter(torch.randn(400, 8, generator=g))
+    cfeats = torch.nn.Parameter(torch.randn(400, 4, generator=g))
+    mlp = [torch.nn.Parameter(torch.randn(16, 8, generator=g)), torch.nn.Parameter(torch.randn(16, generator=g)),
+           torch.nn.Parameter(torch.randn(3, 16, generator=g)), torch.nn.Parameter(torch.randn(3, generator=g))]
+    return feats, cfeats, mlp
+
+
+def _view_loss(feats, cfeats, mlp, view):
+    """A 'view' touches 60 of the 400 neural points; the MLP sees every touched row."""
+    idx = torch.arange(view * 45, view * 45 + 60)
+    h = torch.relu(feats[idx] @ mlp[0].T + mlp[1])
+    return ((h @ mlp[2].T + mlp[3]) ** 2).sum() * (view + 1) + (cfeats[idx] ** 3).sum(), idx
+
+
+def _worker2(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # (a) reference: plain backward + one-shot all-reduce
+        feats, cfeats, mlp = _make_model()
+        loss, idx = _view_loss(feats, cfeats, mlp, rank)
+        loss.backward()
+        pdist.allreduce_grads([feats, cfeats] + mlp)
+        ref = [p.grad.clone() for p in [feats, cfeats] + mlp]
+        # (b) persistent buckets with gradients accumulated in place + overlap hooks; features row-sparse
+        feats, cfeats, mlp = _make_model()
+        b_mlp = pdist.GradBucket(mlp)
+        b_tab = pdist.GradBucket([feats, cfeats], overlap=False)
+        ex = pdist.RowSparseExchange()
+        out = []
+        for _ in range(2):                                          # two steps: the buckets are reusable
+            b_mlp.zero()
+            b_tab.zero()
+            loss, idx = _view_loss(feats, cfeats, mlp, rank)
+            loss.backward()
+            assert feats.grad.data_ptr() == b_tab.views[0].data_ptr()          # written in place, no copy
+            assert mlp[0].grad.data_ptr() == b_mlp.views[0].data_ptr()
+            b_mlp.finish()
+            ex.reduce_(feats.grad, idx)
+            mode_f = ex.last["mode"]
+            ex.reduce_(cfeats.grad, idx)
+            out.append([p.grad.clone() for p in [feats, cfeats] + mlp])
+        # (c) dense fallback of the exchange
+        feats2, cfeats2, mlp2 = _make_model()
+        loss, idx = _view_loss(feats2, cfeats2, mlp2, rank)
+        loss.backward()
+        exd = pdist.RowSparseExchange(dense_threshold=0.01)
+        exd.reduce_(feats2.grad, idx)
+        q.put((rank, [g.numpy() for g in ref], [[g.numpy() for g in o] for o in out], mode_f, exd.last["mode"],
+               feats2.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_buckets_overlap_and_row_sparse_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ref0, out0, mode0, dmode0, fd0), (_, ref1, out1, mode1, dmode1, fd1) = res
+    assert mode0 == mode1 == "sparse" and dmode0 == dmode1 == "dense"
+    for step in range(2):
+        for a, b, r in zip(out0[step], out1[step], ref0):
+            assert (a == b).all()                                  # bit-identical on both ranks
+            assert (a == r).all()                                  # world 2: a + b is one rounding, so == the dense mean
+    assert (fd0 == ref0[0]).all() and (fd1 == ref0[0]).all()
+
+
+def test_world_size_one_bucket_step_is_bit_identical_to_plain_step():
+    """North-star: with one view per step no collective is issued and the step is bit-for-bit the single-GPU one."""
+    feats, cfeats, mlp = _make_model()
+    loss, _ = _view_loss(feats, cfeats, mlp, 1)
+    loss.backward()
+    plain = [p.grad.clone() for p in [feats, cfeats] + mlp]
+    feats, cfeats, mlp = _make_model()
+    b = pdist.GradBucket([feats, cfeats] + mlp)
+    b.zero()
+    loss, idx = _view_loss(feats, cfeats, mlp, 1)
+    loss.backward()
+    b.finish()
+    pdist.RowSparseExchange().reduce_(feats.grad, idx)
+    for a, p in zip(plain, [feats, cfeats] + mlp):
+        assert torch.equal(a, p.grad)
+    assert b._work is None

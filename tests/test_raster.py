@@ -185,31 +185,29 @@ def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size
     assert (mv.cpu() == R.mark_visible(F32(sc["means"]), so)).all()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel"])
-@pytest.mark.parametrize("mode,front_only,seed", CASES + [("surfel", True, 31), ("3dgs", True, 32)])
-def test_gradients_match_fp64_oracle(mode, front_only, seed, bwd_kernel, monkeypatch):
-    """Both blend-backward kernels (Gaussian-per-lane wave scans / pixel-per-lane reduce) against the fp64 oracle."""
-    from pings_amd import rasterizer as hr
-
-    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel)
-
-    sc = make_scene(400, 80, 64, seed=seed, surfel=(mode == "surfel"))
-    dt = torch.float64
+def _oracle_grads(sc, dt, mode, front_only, seeds=5):
+    """Oracle forward + autograd backward in dtype `dt` against fixed random upstream gradients."""
     o, leaves, theta, rho = _oracle(sc, dt, mode, front_only, grads=True)
     H, W = sc["H"], sc["W"]
-    g = torch.Generator().manual_seed(5)
-    gc, gn = torch.randn(3, H, W, generator=g, dtype=dt), torch.randn(3, H, W, generator=g, dtype=dt)
-    gd, ga = torch.randn(1, H, W, generator=g, dtype=dt), torch.randn(1, H, W, generator=g, dtype=dt)
-    loss = (o["color"] * gc).sum() + (o["depth"] * gd).sum() + (o["alpha"] * ga).sum()
+    g = torch.Generator().manual_seed(seeds)
+    f64 = torch.float64
+    gc, gn = torch.randn(3, H, W, generator=g, dtype=f64), torch.randn(3, H, W, generator=g, dtype=f64)
+    gd, ga = torch.randn(1, H, W, generator=g, dtype=f64), torch.randn(1, H, W, generator=g, dtype=f64)
+    loss = (o["color"] * gc.to(dt)).sum() + (o["depth"] * gd.to(dt)).sum() + (o["alpha"] * ga.to(dt)).sum()
     if mode == "surfel":
-        loss = loss + (o["normal"] * gn).sum()
+        loss = loss + (o["normal"] * gn.to(dt)).sum()
     ref = torch.autograd.grad(loss, list(leaves.values()) + [theta, rho])
+    return o, list(leaves) + ["theta", "rho"], ref, (gc, gn, gd, ga)
 
+
+def _hip_grads(sc, mode, front_only, ups):
+    from pings_amd import rasterizer as hr
+
+    gc, gn, gd, ga = ups
     Rz = hr.SurfelGaussianRasterizer if mode == "surfel" else hr.GS3DGaussianRasterizer
     rast = Rz(hip_settings(sc, mode, front_only))
     d = lambda t: t.to(torch.float32).cuda().contiguous().requires_grad_(True)
-    hl = {k: d(sc[k]) for k in leaves}
+    hl = {k: d(sc[k]) for k in ["means", "col", "op", "scales", "rot"]}
     m2d = torch.zeros_like(hl["means"], requires_grad=True)
     th = torch.zeros(3, device="cuda", requires_grad=True)
     rh = torch.zeros(3, device="cuda", requires_grad=True)
@@ -223,13 +221,111 @@ def test_gradients_match_fp64_oracle(mode, front_only, seed, bwd_kernel, monkeyp
         img, radii, dep, alp, nt = out
         hloss = (img * f(gc)).sum() + (dep * f(gd)).sum() + (alp * f(ga)).sum()
     hloss.backward()
-    got = [hl[k].grad for k in leaves] + [th.grad, rh.grad]
-    # tolerance: 1e-4 relative (north_star), x3 head-room for the fp32 evaluation of grazing
-    # surfels (the fp32 oracle itself differs from the fp64 one by that much there).
-    tol = 3e-4
-    for name, a, b in zip(list(leaves) + ["theta", "rho"], got, ref):
-        assert rel_err(a, b) <= tol, (name, rel_err(a, b))
+    return out, [hl[k].grad for k in hl] + [th.grad, rh.grad], m2d
+
+
+def _assert_grad_gate(names, got, ref64, ref32, what):
+    """The gate VERDICT r1 asks for: 1e-4 relative (north_star), relaxed per tensor only as far as the fp32 ORACLE
+    itself is away from the fp64 one on the same inputs (x1.5) — grazing surfels make the fp32 evaluation of the
+    published backward that ill-conditioned — with both errors printed."""
+    rows = []
+    for name, a, b64, b32 in zip(names, got, ref64, ref32):
+        e_hip, e_o32 = rel_err(a, b64), rel_err(b32, b64)
+        rows.append((name, e_hip, e_o32))
+    print(f"\n[{what}] gradient errors vs the fp64 oracle   (HIP fp32 | fp32 oracle)")
+    for name, e_hip, e_o32 in rows:
+        print(f"  {name:7s} {e_hip:9.2e} | {e_o32:9.2e}")
+    for name, e_hip, e_o32 in rows:
+        assert e_hip <= max(1e-4, 1.5 * e_o32), (what, name, e_hip, e_o32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel"])
+@pytest.mark.parametrize("mode,front_only,seed", CASES + [("surfel", True, 31), ("3dgs", True, 32)])
+def test_gradients_match_fp64_oracle(mode, front_only, seed, bwd_kernel, monkeypatch):
+    """Both blend-backward kernels (Gaussian-per-lane wave scans / pixel-per-lane reduce) against the fp64 oracle:
+    1e-4 relative per gradient tensor, or 1.5x the fp32 oracle's own distance from the fp64 one where that is larger."""
+    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel)
+    sc = make_scene(400, 80, 64, seed=seed, surfel=(mode == "surfel"))
+    _, names, ref64, ups = _oracle_grads(sc, torch.float64, mode, front_only)
+    _, _, ref32, _ = _oracle_grads(sc, torch.float32, mode, front_only)
+    _, got, m2d = _hip_grads(sc, mode, front_only, ups)
+    _assert_grad_gate(names, got, ref64, ref32, f"{mode} front_only={front_only} seed={seed} {bwd_kernel}")
     assert m2d.grad is not None and m2d.grad[:, 2].abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,P,W,H,fx", [("street", 24000, 348, 128, 180.0), ("room", 24000, 320, 240, 300.0),
+                                            ("cloud", 16000, 480, 272, 250.0)])
+def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
+    """Parity at a realistic density: surface-like street / room scenes and the bench's own
+    16k-Gaussian cloud at 480x272 — images <= 1e-4 vs the fp64 oracle, lists bit-exact prefixes of the fp32
+    oracle's, every gradient under the gate above."""
+    import bench
+    from scenes import room_scene, scene_as_dict, street_scene
+
+    if kind == "cloud":
+        parts = bench.synth_cloud(P, W, H, fx, fx, "cpu", seed=42)
+    else:
+        parts = (street_scene if kind == "street" else room_scene)(P, device="cpu", seed=3)
+    sc = scene_as_dict(*parts, W, H, fx)
+    o32, *_ = _oracle(sc, torch.float32, "surfel", True)
+    o64, names, ref64, ups = _oracle_grads(sc, torch.float64, "surfel", True)
+    _, _, ref32, _ = _oracle_grads(sc, torch.float32, "surfel", True)
+    hr, prep, fs, radii, per_g = _hip_forward(sc, "surfel", True)
+    pl, rg, fT, nc = hr.debug_lists(fs)
+    assert (radii.cpu() == o32["radii"]).all()
+    _check_list_prefixes(pl, rg, nc, o32, W, H)
+    assert (nc.cpu() == o32["n_contrib"]).all()
+    for k, t in (("color", fs.color), ("depth", fs.depth), ("alpha", fs.alpha), ("normal", fs.normal)):
+        assert rel_err(t, o64[k]) <= 1e-4, k
+    assert rel_err(per_g, o64["contributions"]) <= 1e-4
+    _, got, _ = _hip_grads(sc, "surfel", True, ups)
+    _assert_grad_gate(names, got, ref64, ref32, f"{kind} {P}@{W}x{H}")
+
+
+@pytest.mark.gpu
+def test_tile_rectangle_variant_3sigma_square(monkeypatch):
+    """DESIGN §3 assumption 1 kept measurable: with PINGS_RASTER_RECT=3sigma the kernel emits the published 3DGS
+    tile square; its lists are bit-exact the oracle's `rect="3sigma"` lists, the default (ellipse bounding box) lists
+    are sub-lists of them, and the images of the two variants differ only by the alpha < ~0.011 tail."""
+    P, W, H = 1500, 200, 120
+    sc = make_scene(P, W, H, seed=61)
+    monkeypatch.setenv("PINGS_RASTER_OCCLUSION", "0")
+    hr, prep, fs_e, radii_e, _ = _hip_forward(sc, "surfel", True)
+    col_e, alp_e, I_e = fs_e.color.clone(), fs_e.alpha.clone(), fs_e.I
+    monkeypatch.setenv("PINGS_RASTER_RECT", "3sigma")
+    hr, prep, fs_s, radii_s, _ = _hip_forward(sc, "surfel", True)
+    so = oracle_settings(sc, torch.float32, "surfel", True)
+    so.rect = "3sigma"
+    names = ["means", "col", "op", "scales", "rot"]
+    o = R.rasterize(*[sc[k].float() for k in names], so, return_debug=True)
+    pl, rg, fT, nc = hr.debug_lists(fs_s)
+    assert (radii_s.cpu() == o["radii"]).all()
+    assert fs_s.I == len(o["point_list"]) and np.array_equal(pl.cpu().numpy(), o["point_list"])
+    assert np.array_equal(rg.cpu().numpy(), o["ranges"])
+    assert (nc.cpu() >= 0).all() and I_e < fs_s.I
+    d_col = (fs_s.color - col_e).abs().max().item()
+    d_alp = (fs_s.alpha - alp_e).abs().max().item()
+    print(f"\n[rect variants] instances ellipse {I_e} vs 3sigma square {fs_s.I}; max |d colour| {d_col:.2e}, "
+          f"max |d alpha| {d_alp:.2e}")
+    assert d_col <= 0.05 and d_alp <= 0.05            # only the truncated low-alpha tail differs
+    o64, *_ = _oracle(sc, torch.float64, "surfel", True)
+    assert rel_err(col_e, o64["color"]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_mark_visible_depth_only_variant(monkeypatch):
+    """DESIGN §3 assumption 2 kept switchable: PINGS_MARK_VISIBLE=depth == oracle mark_visible(mark_frustum=False)."""
+    sc = make_scene(800, 96, 64, seed=16)
+    hr, prep, *_ = _hip_forward(sc, "surfel", True)
+    so = oracle_settings(sc, torch.float32)
+    full = hr.mark_visible(sc["means"].float().cuda(), prep).cpu()
+    monkeypatch.setenv("PINGS_MARK_VISIBLE", "depth")
+    dep = hr.mark_visible(sc["means"].float().cuda(), prep).cpu()
+    so.mark_frustum = False
+    assert (dep == R.mark_visible(F32(sc["means"]), so)).all()
+    assert (full <= dep).all() and int(dep.sum()) > int(full.sum())
 
 
 @pytest.mark.gpu
@@ -300,18 +396,30 @@ def test_dropin_module_names_resolve():
     assert callable(fs.fused_ssim)
 
 
+FULL_SIZE = [  # BASELINE.json configs at their full sizes: workload, P, W, H, fx
+    ("metric1_cloud", 1_000_000, 1920, 1080, 1000.0),    # headline: 1M Gaussians, 1080p, the bench.py cloud
+    ("c2_room", 200_000, 640, 480, 600.0),               # C2: Replica RGB-D, ~200k Gaussians, 640x480
+    ("c3_street", 1_000_000, 1392, 512, 720.0),          # C3: KITTI, ~1M Gaussians, 1392x512
+]
+
+
 @pytest.mark.gpu
-def test_full_size_properties_1m_gaussians_1080p():
-    """BASELINE.json size (1M Gaussians, 1920x1080, the bench.py cloud): size-independent properties —
-    per-tile lists sorted by (depth, index) and consistent with the tile ranges, bounded outputs, background
-    where nothing was blended, backward linear in the upstream gradient, bitwise determinism."""
+@pytest.mark.parametrize("workload,P,W,H,fx", FULL_SIZE)
+def test_full_size_properties(workload, P, W, H, fx):
+    """BASELINE.json sizes (the oracle cannot run there): size-independent properties — per-tile lists sorted by
+    (depth, index) and consistent with the tile ranges, every blended record kept by the occlusion bound, bounded
+    outputs, background where nothing was blended, sum of blend weights == sum of alpha, backward linear in the
+    upstream gradient, bitwise determinism of both backward kernels."""
     import bench
     from pings_amd import rasterizer as hr
+    from scenes import room_scene, street_scene
 
     dev = torch.device("cuda")
-    P, W, H = 1_000_000, 1920, 1080
-    fx = fy = 1000.0
-    means, col, op, scales, rot = bench.synth_cloud(P, W, H, fx, fy, dev)
+    fy = fx
+    if workload == "metric1_cloud":
+        means, col, op, scales, rot = bench.synth_cloud(P, W, H, fx, fy, dev)
+    else:
+        means, col, op, scales, rot = (room_scene if workload == "c2_room" else street_scene)(P, device=dev, seed=1)
     cam = bench.camera(W, H, fx, fy, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, 0, dev)
     rs = hr.SurfelRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.ones(3, device=dev),
@@ -369,13 +477,23 @@ def test_full_size_properties_1m_gaussians_1080p():
     finally:
         del os.environ["PINGS_BLEND_BWD"]
     ga, gb = grads(G1), grads(G2)
+    # the two backward kernels sum the same fp32 terms in different orders, and linearity is exact only up to
+    # fp32 rounding of sums over up to ~1e5 pixels per Gaussian: 5e-4 of the largest entry bounds both (the parity
+    # gates against the oracle are in test_gradients_match_fp64_oracle / test_mid_size_scene_*)
+    worst = [0.0, 0.0]
     for a, b, c in zip(gs1, gs2, ga):
         assert torch.equal(a, b)                                          # scan kernel: bitwise reproducible
-        assert (a.double() - c.double()).abs().max().item() <= 5e-4 * max(c.double().abs().max().item(), 1e-20)
+        e = (a.double() - c.double()).abs().max().item() / max(c.double().abs().max().item(), 1e-20)
+        worst[0] = max(worst[0], e)
+        assert e <= 5e-4
     gc = grads([2.0 * a - 0.5 * b for a, b in zip(G1, G2)])
     for a, b, c in zip(ga, gb, gc):
         ref = 2.0 * a.double() - 0.5 * b.double()
-        assert (c.double() - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-20)
+        e = (c.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-20)
+        worst[1] = max(worst[1], e)
+        assert e <= 5e-4
+    print(f"\n[{workload}] I={fs.I} longest list {int(lens.max())}; scan-vs-pixel kernel {worst[0]:.1e}, "
+          f"linearity {worst[1]:.1e}")
     for a, b in zip(ga, grads(G1)):
         assert torch.equal(a, b)
 

@@ -261,3 +261,102 @@ def test_hip_fused_sdf_backward_matches_oracle_autograd(golden_dir, name):
         assert rel_err(a.reshape(b.shape), b) <= 1e-4, nm          # tolerance: north_star 1e-4 rel
     for a, b in zip(*outs):
         assert torch.equal(a, b)                                   # bitwise reproducible scatter
+
+
+# ------------------------------------------------------------------ HIP map update followed by HIP queries
+def _dress_map(m, nn_k=6, search_alpha=0.8):
+    """Give a `neural_map.new_map` attribute bag the query-side attributes of the reference's NeuralPoints."""
+    from types import SimpleNamespace
+
+    dev = m.neural_points.device
+    m.neighbor_dx = sdf_cpu.neighbor_offsets(2, search_alpha).to(dev)
+    m.max_valid_dist2 = 3 * ((2 + 1) * m.resolution) ** 2
+    m.after_pgo = False
+    m.nn_k = nn_k
+    m.weighted_first = False
+    m.dtype = torch.float32
+    m.config = SimpleNamespace(query_nn_k=nn_k, weighted_first=False, layer_norm_on=False)
+    return m
+
+
+def _state_of(m):
+    """CPU state dict of a HIP map for oracle/sdf_cpu.NeuralPointMap."""
+    c = lambda t: t.detach().cpu().numpy()
+    return dict(buffer_size=int(m.buffer_size), buffer_pt_index=c(m.buffer_pt_index), neural_points=c(m.neural_points),
+                point_orientations=c(m.point_orientations), geo_features=c(m.geo_features),
+                point_ts_create=c(m.point_ts_create), point_certainties=c(m.point_certainties),
+                free_gs_mask=c(m.free_gs_mask), valid_gs_mask=c(m.valid_gs_mask), travel_dist=c(m.travel_dist),
+                cur_ts=int(m.cur_ts), diff_travel_dist_local=float(m.diff_travel_dist_local),
+                local_neural_points=c(m.local_neural_points), local_point_orientations=c(m.local_point_orientations),
+                local_geo_features=c(m.local_geo_features), local_point_certainties=c(m.local_point_certainties),
+                local_point_ts_update=c(m.local_point_ts_update), global2local=c(m.global2local),
+                neighbor_dx=c(m.neighbor_dx), max_valid_dist2=m.max_valid_dist2, resolution=m.resolution,
+                after_pgo=False, temporal_local_map_on=bool(m.temporal_local_map_on), nn_k=m.nn_k, weighted_first=False)
+
+
+@pytest.mark.gpu
+def test_hip_query_sees_points_inserted_by_hip_update(monkeypatch):
+    """`pings_map_update` writes the hash table through its raw pointer, which torch's version
+    counter cannot see; the query path's compact mirror must still follow.  update -> query -> update (new points,
+    overwritten slots) -> query on ONE map object: compact-mirror results == dense-table results == CPU oracle."""
+    from pings_amd import neural_map as NM
+    from pings_amd import neural_points as hnp
+
+    g = torch.Generator().manual_seed(9)
+    m = NM.new_map(200_003, 8, 4, 0.25, temporal_local_map_on=True, local_map_radius=30.0,
+                   sorrounding_map_radius=40.0, diff_travel_dist_local=100.0, device="cuda")   # small table: collisions
+    m.geo_feature_std = 0.05
+    m.travel_dist = torch.arange(4, dtype=torch.float32, device="cuda")
+    _dress_map(m)
+    dec = _Dec({"dec.layers.0.weight": 0.3 * torch.randn(64, 11, generator=g).numpy(),
+                "dec.layers.0.bias": 0.1 * torch.randn(64, generator=g).numpy(),
+                "dec.lout.weight": 0.3 * torch.randn(1, 64, generator=g).numpy(),
+                "dec.lout.bias": np.zeros(1, np.float32), "sdf_scale": 0.03})
+    sensor = torch.zeros(3, device="cuda")
+    seen = []
+    for ts in range(3):
+        xy = (torch.rand(40_000, 2, generator=g) - 0.5) * 24.0 + torch.tensor([6.0 * ts, 0.0])
+        pts = torch.cat([xy, (torch.sin(0.5 * xy[:, :1]) + 0.01 * torch.randn(40_000, 1, generator=g))], 1).cuda()
+        NM.update(m, pts, torch.rand(40_000, 3, generator=g).cuda(), None, sensor, None, cur_ts=ts)
+        n = int(m.neural_points.shape[0])
+        seen.append(n)
+        x = (m.neural_points[torch.randint(0, n, (3000,), generator=g).cuda()]
+             + 0.1 * torch.randn(3000, 3, generator=g).cuda()).contiguous()
+        monkeypatch.setattr(hnp, "USE_COMPACT_TABLE", True)
+        hi, hd, hc = hnp.radius_neighborhood_topk(m, x, time_filtering=True, query_locally=True)
+        s_c, _, c_c, _ = hnp.sdf_fused(m, dec, x)
+        monkeypatch.setattr(hnp, "USE_COMPACT_TABLE", False)
+        di, dd, dc = hnp.radius_neighborhood_topk(m, x, time_filtering=True, query_locally=True)
+        s_d, _, c_d, _ = hnp.sdf_fused(m, dec, x)
+        assert torch.equal(hi, di) and torch.equal(hd, dd) and torch.equal(hc, dc), f"frame {ts}: stale mirror"
+        assert torch.equal(s_c, s_d) and torch.equal(c_c, c_d)
+        cpu = sdf_cpu.NeuralPointMap(_state_of(m))
+        ri, rd, rc = cpu.search_topk(x.cpu())
+        assert torch.equal(hi.cpu(), ri) and torch.equal(hc.cpu(), rc) and torch.equal(hd.cpu(), rd)
+        # the newest points are found: a query sitting exactly on the last inserted point returns it first
+        last = m.neural_points[n - 1:n].contiguous()
+        li, ld, _ = hnp.radius_neighborhood_topk(m, last, time_filtering=True, query_locally=False,
+                                                 use_only_measured_points=False)
+        assert int(li[0, 0]) == n - 1 and float(ld[0, 0]) == 0.0
+    assert seen[0] < seen[1] < seen[2]
+
+
+@pytest.mark.gpu
+def test_hip_fused_sdf_5m_point_map_against_oracle():
+    """BASELINE.json config C5 shape on one GPU (5M neural points, 1e8-slot table, K=81, k=6): neighbour indices,
+    counts and fp32 squared distances index-/bit-exact on 4,096 queries vs oracle/sdf_cpu.py, SDF <= 1e-4."""
+    from pings_amd import neural_points as hnp
+
+    st, dec = sdf_cpu.synthetic_map(5_000_000)
+    x = sdf_cpu.synthetic_queries(st, 4096)
+    cpu = sdf_cpu.NeuralPointMap({**st})
+    assert cpu.neural_points.shape[0] == 5_000_000
+    ri, rd, rc = cpu.search_topk(x, use_only_measured_points=False)
+    s_ref, _ = sdf_cpu.mapper_sdf(cpu, sdf_cpu.MLP.from_state({**dec}), x)
+    del cpu
+    gpu = _gpu_map({**st})
+    hi, hd, hc = hnp.radius_neighborhood_topk(gpu, x.cuda(), query_locally=True)
+    assert torch.equal(hi.cpu(), ri) and torch.equal(hc.cpu(), rc) and torch.equal(hd.cpu(), rd)
+    sdf, grad, cnt, _ = hnp.sdf_fused(gpu, _Dec({**dec}), x.cuda(), need_grad=True, use_only_measured_points=False)
+    assert rel_err(sdf, s_ref) <= 1e-4 and torch.isfinite(grad).all()
+    assert float((cnt > 0).float().mean()) > 0.95
