@@ -222,6 +222,85 @@ PINGS_API int pings_knn_search(const pings_knn_map* m, const float* queries, int
                                int64_t* idx, float* d2, int64_t* nn_counts, int64_t* global_idx,
                                void* stream);
 
+/* ---- NeuralPoints.query_feature (model/neural_gaussians.py:506-725): forward, backward, double backward ----
+ * The tables are the LOCAL ones for a local query (local_geo_features [N_local+1, Fg], local_color_features,
+ * local_neural_points, local_point_orientations, local_point_certainties) or the global ones; `m` carries the
+ * search-side tensors (always the global neural_points / table / masks, plus global2local for a local query). */
+typedef struct pings_qf_tables {
+  const float* geo_features;    /* [rows, Fg] or NULL (query_geo_feature = False)                       */
+  const float* color_features;  /* [rows, Fc] or NULL (query_color_feature = False / no colour table)   */
+  int32_t Fg, Fc;               /* 0 when the table is NULL                                             */
+  const float* points;          /* [rows - 1 .. rows, 3] positions in the index space of the features   */
+  const float* orientations;    /* [.., 4] wxyz, read only when after_pgo (:627-630)                    */
+  const float* certainties;     /* [..] read for the queried certainty (:691-695); may be NULL          */
+  int32_t after_pgo;
+  int32_t weighted_first;       /* config.weighted_first (:701-705): outputs are [B, F+3] weighted sums */
+} pings_qf_tables;
+
+/* Forward.  geo_out / color_out: [B, nn_k, F+3] (or [B, F+3] when weighted_first), NULL = not queried;
+ * w_out [B, nn_k] normalised inverse-distance weights (:644-662; all 0 for a query without neighbours);
+ * idx_out / gidx_out [B, nn_k] int64 (-1 = none): rows of the queried tables / of the global point array
+ * (they differ for a local query: the weights are measured to the GLOBAL point, :1098-1101);
+ * nn_counts [B] int64 over all K cells (:557); certainty [B] (optional).
+ * Side effects of training mode (:664-689), each optional: certainty_accum[row] += w (float atomics, as the
+ * reference's scatter_add_; pass a zeroed DELTA buffer distinct from t->certainties and add it to the table
+ * afterwards: the queried certainty must see the values from before the accumulation, :615-620 vs :664-689),
+ * ts_update[row] = max(ts_update[row], query_ts[b]) (integer atomics, exact). */
+PINGS_API int pings_query_feature_forward(const pings_knn_map* m, const pings_qf_tables* t, const float* queries,
+                                          int64_t B, float* geo_out, float* color_out, float* w_out,
+                                          int64_t* idx_out, int64_t* gidx_out, int64_t* nn_counts,
+                                          float* certainty, float* certainty_accum, const int32_t* query_ts,
+                                          int32_t* ts_update, float* n_out, void* stream);
+/* n_out [B, nn_k, 3] (optional): the neighbour vectors on their own (they are also columns F..F+2 of the rows). */
+
+/* Backward: upstream g_geo / g_color (shapes of the forward outputs, NULL = none) and g_w [B, nn_k] ->
+ * g_x [B,3] (through the neighbour vectors AND the weights; squared distances stay in the graph, :1099-1101),
+ * g_geo_features [rows, Fg] / g_color_features [rows, Fc] (dense, every row written; NULL = not wanted):
+ * the deterministic row scatter-add of the upstream gradient (pings_rows_scatter_add).
+ * `global_points` = m->neural_points of the forward.  scratch: pings_query_feature_scratch_bytes(B, nn_k, rows). */
+PINGS_API size_t pings_query_feature_scratch_bytes(int64_t B, int nn_k, int64_t rows);
+PINGS_API int pings_query_feature_backward(const pings_qf_tables* t, const float* global_points,
+                                           const float* queries, int64_t B, int nn_k, const int64_t* idx,
+                                           const int64_t* gidx, const float* g_geo, const float* g_color,
+                                           const float* g_n, const float* g_w, int64_t rows, void* scratch,
+                                           float* g_x, float* g_geo_features, float* g_color_features,
+                                           void* stream);
+/* Split layout (per-neighbour mode): g_n [B, nn_k, 3] != NULL carries the neighbour-vector part of the upstream
+ * gradient on its own (g_geo / g_color are then ignored and the feature rows are scattered separately with
+ * pings_rows_plan_build / _apply) — the autograd wrapper keeps the table path and the query path in separate graph
+ * nodes so that get_gradient(x, sdf) does not pay for a table scatter nobody asked for. */
+
+/* Backward of the backward (get_gradient(..., create_graph=True), utils/tools.py:409-419; used by
+ * utils/mapper.py:874-875,:1445-1448): given gg_x [B,3] (and, optionally, gg_*_features [rows, F]) — the
+ * gradients w.r.t. the backward's outputs — the gradients w.r.t. its inputs: d_g_geo / d_g_color (shapes of
+ * g_geo / g_color), d_g_w [B, nn_k], d_x [B,3] (optional) and, in weighted_first mode only, the feature tables
+ * d_geo_features / d_color_features [rows, F] (per-neighbour mode: the backward does not depend on them). */
+PINGS_API int pings_query_feature_double_backward(
+    const pings_qf_tables* t, const float* global_points, const float* queries, int64_t B, int nn_k,
+    const int64_t* idx, const int64_t* gidx, const float* g_geo, const float* g_color, const float* g_w,
+    const float* gg_x, const float* gg_geo_features, const float* gg_color_features, int64_t rows, void* scratch,
+    float* d_g_geo, float* d_g_color, float* d_g_n, float* d_g_w, float* d_x, float* d_geo_features,
+    float* d_color_features, void* stream);
+/* d_g_n [B, nn_k, 3] (split layout, see above): replaces d_g_geo / d_g_color. */
+
+/* Deterministic scatter-add of rows — the backward of a row gather `table[idx]`
+ * (model/neural_gaussians.py:565-579; the reference's autograd uses atomics there):
+ *   out[r, 0:F] = sum over pairs p with dst_row[p] == r, in ascending p, of w[p] * src[src_row[p] * ld + 0:F]
+ * and 0 for rows nothing points at (every row of out[rows, F] is written; no memset needed).
+ * dst_row[p] < 0 or >= rows skips the pair; w == NULL: weight 1; src_row == NULL: pair p reads row p.
+ * F <= 64.  Counting sort by destination (integer atomics only) + one pass over the table: bitwise
+ * reproducible.  `scratch`: pings_rows_scatter_add_scratch_bytes(n_pairs, rows) bytes. */
+PINGS_API size_t pings_rows_scatter_add_scratch_bytes(int64_t n_pairs, int64_t rows);
+PINGS_API int pings_rows_scatter_add(const int64_t* dst_row, int64_t n_pairs, const float* src, int64_t ld,
+                                     int32_t F, const float* w, const int64_t* src_row, int64_t rows,
+                                     void* scratch, float* out, void* stream);
+/* The same in two steps for several tables sharing one destination index: `plan` (caller-owned,
+ * pings_rows_plan_bytes(n_pairs, rows) bytes) is built once and applied per table; pair p reads row p of src. */
+PINGS_API size_t pings_rows_plan_bytes(int64_t n_pairs, int64_t rows);
+PINGS_API int pings_rows_plan_build(const int64_t* dst_row, int64_t n_pairs, int64_t rows, void* plan, void* stream);
+PINGS_API int pings_rows_plan_apply(const void* plan, int64_t n_pairs, int64_t rows, const float* src, int64_t ld,
+                                    int32_t F, const float* w, float* out, void* stream);
+
 typedef struct pings_sdf_decoder {
   const float* W1;   /* [hidden, F+3] layers.0.weight (decoder.py:49) */
   const float* b1;   /* [hidden]                                      */
@@ -252,10 +331,12 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
  * (the training path of Mapper.sdf_mapping, utils/mapper.py:822-970: loss(sdf).backward()).
  *   dL_dfeatures[rows,F]  dense, zero where no query touched the row
  *   dL_dW1[H,F+3], dL_db1[H], dL_dW2[H], dL_db2[1]
- * Deterministic: per-(query, neighbour) gradient rows are written once, sorted by destination
- * (radix sort) and summed in sorted order; decoder gradients are per-workgroup partials summed in
- * fixed order.  `scratch` needs pings_sdf_backward_scratch_bytes(B, nn_k, F, H) bytes. */
-PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden);
+ * Deterministic: per-(query, neighbour) gradient rows are written once, grouped by destination row
+ * (counting sort, pings_rows_scatter_add below) and summed in ascending pair order; decoder gradients
+ * are per-workgroup partials summed in fixed order.
+ * `scratch` needs pings_sdf_backward_scratch_bytes(B, nn_k, F, H, feature_rows) bytes. */
+PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden,
+                                                  int64_t feature_rows);
 PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* features,
                                  int64_t feature_rows, const float* points,
                                  const float* orientations, int32_t after_pgo, const float* queries,

@@ -83,10 +83,9 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.occ_bsat = c.take<uint16_t>(nt);
   g.nvalid = c.take<uint32_t>(1);
   const size_t nblk = (n + 255) / 256;                  // workgroups of the per-Gaussian kernels
-  g.ds_words = DS_HEAD + 2 * (size_t)DS_NB + nblk;      // header, counts (+ per-block culled), fill cursors: one memset
+  g.ds_words = DS_HEAD + (size_t)DS_NB + nblk;          // header, counts (+ per-block culled): one memset
   g.ds_head = c.take<uint32_t>(g.ds_words);
   g.ds_cnt = g.ds_head ? g.ds_head + DS_HEAD : nullptr;
-  g.ds_fill = g.ds_head ? g.ds_cnt + DS_NB + nblk : nullptr;
   g.ds_off = c.take<uint32_t>((size_t)DS_NB + nblk + 1);
   g.ds_idx = c.take<uint32_t>(n);
   g.stats = c.take<unsigned long long>(2 * 256);  // sharded {pairs before culling, visible Gaussians}
@@ -457,25 +456,49 @@ __global__ __launch_bounds__(64) void ds_range_kernel(uint32_t* __restrict__ hea
 }
 
 // bucket histogram of the survivors; culled Gaussians are counted per workgroup (cnt[DS_NB + block]) so that the one
-// exclusive scan over [bucket counts | per-block culled counts] also yields each block's first culled rank
+// exclusive scan over [bucket counts | per-block culled counts] also yields each block's first culled rank.
+// The histogram atomics are aggregated per wave: lanes that fall into the same bucket elect a leader (pure ALU
+// rounds: ballot of the lanes equal to the first unassigned one), the leaders issue ONE returning atomic per distinct
+// bucket, all in flight together, and every lane derives its arrival slot inside the bucket (`pos`) from the leader's
+// return value.  A wall of surfels at one depth — a quarter of a million Gaussians in one bucket — would otherwise
+// serialise on one address (~12 ns per atomic: 3 ms); the scatter pass needs no atomics at all.
 __global__ __launch_bounds__(256) void ds_hist_kernel(int P, const uint32_t* __restrict__ key, const uint32_t* __restrict__ head,
-                                                       uint32_t* __restrict__ cnt) {
+                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ pos) {
   __shared__ uint32_t sc[4];
   const int g = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const uint32_t k = g < P ? key[g] : 0u;
   const bool culled = g < P && k == CULLED_KEY;
-  if (g < P && !culled) {
-    const DsRange r = ds_range(head);
-    atomicAdd(&cnt[(k - r.kmin) >> r.shift], 1u);
+  const bool active = g < P && !culled;
+  const DsRange r = ds_range(head);
+  const uint32_t b = active ? (k - r.kmin) >> r.shift : 0xFFFFFFFFu;
+  unsigned long long todo = __ballot(active);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int my_leader = lane;
+  uint32_t my_rank = 0u, group = 0u;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+    const unsigned long long m = __ballot(b == lb) & todo;
+    if (b == lb) {
+      my_leader = leader;
+      my_rank = (uint32_t)__popcll(m & below);
+      group = (uint32_t)__popcll(m);
+    }
+    todo &= ~m;
   }
+  uint32_t base = 0u;
+  if (active && my_leader == lane) base = atomicAdd(&cnt[b], group);
+  base = (uint32_t)__shfl((int)base, my_leader, 64);
+  if (active) pos[g] = base + my_rank;
   const unsigned long long bal = __ballot(culled);
-  if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+  if (lane == 0) sc[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
   __syncthreads();
   if (threadIdx.x == 0) cnt[DS_NB + blockIdx.x] = (sc[0] + sc[1]) + (sc[2] + sc[3]);
 }
 
 __global__ __launch_bounds__(256) void ds_scatter_kernel(int P, const uint32_t* __restrict__ key, const uint32_t* __restrict__ head,
-                                                          const uint32_t* __restrict__ off, uint32_t* __restrict__ fill,
+                                                          const uint32_t* __restrict__ off, const uint32_t* __restrict__ pos,
                                                           uint32_t* __restrict__ tmp_key, uint32_t* __restrict__ tmp_idx,
                                                           uint32_t* __restrict__ gidx_sorted) {
   __shared__ uint32_t sc[4];
@@ -486,7 +509,7 @@ __global__ __launch_bounds__(256) void ds_scatter_kernel(int P, const uint32_t* 
   if (g < P && !culled) {
     const DsRange r = ds_range(head);
     const uint32_t b = (k - r.kmin) >> r.shift;
-    const uint32_t slot = off[b] + atomicAdd(&fill[b], 1u);
+    const uint32_t slot = off[b] + pos[g];
     tmp_key[slot] = k;
     tmp_idx[slot] = (uint32_t)g;
   }
@@ -1352,10 +1375,11 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
       PINGS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ds_range_kernel, dim3(1), dim3(64), 0, st, gs.ds_head);
       PINGS_LAUNCH_CHECK();
-      hipLaunchKernelGGL(ds_hist_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_cnt);
+      // arrival slots of the survivors live in rank_of until ds_rank_kernel overwrites it with the final ranks
+      hipLaunchKernelGGL(ds_hist_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_cnt, gs.rank_of);
       PINGS_LAUNCH_CHECK();
       PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(gs.temp, tb, gs.ds_cnt, gs.ds_off, DS_NB + (int)grid.x + 1, st));
-      hipLaunchKernelGGL(ds_scatter_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_off, gs.ds_fill,
+      hipLaunchKernelGGL(ds_scatter_kernel, grid, block, 0, st, P, gs.depth_key, gs.ds_head, gs.ds_off, gs.rank_of,
                          gs.depth_key_sorted, gs.ds_idx, gs.gidx_sorted);
       PINGS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ds_rank_kernel, grid, block, 0, st, gs.depth_key_sorted, gs.ds_idx, gs.ds_head, gs.ds_off,

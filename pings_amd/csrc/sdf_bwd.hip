@@ -8,13 +8,14 @@
 //                       gradient, and the (destination feature row, source row) pairs of the scatter.
 //   pings_mlp_backward  the MFMA decoder backward (csrc/mlp.hip) on those rows: dL/d(input rows) and the decoder
 //                       gradients (per-workgroup partials, fixed-order sum).
-//   radix sort + seg_sum_kernel
-//                       every destination's run of source rows is summed in sorted order by a 32-lane group
-//                       and stored once: the scatter-add of the feature gradient without atomics, bitwise
-//                       reproducible (the reference's index_put / scatter_add backward is not).
-#include <hipcub/hipcub.hpp>
-
+//   pings_rows::build + gather_sum (csrc/row_scatter.hip)
+//                       counting sort of the (destination row, source row) pairs and one pass over the feature-
+//                       gradient table that sums every row's pairs in ascending pair id and stores the row once
+//                       (zeros where nothing points): the scatter-add of the feature gradient without float atomics,
+//                       bitwise reproducible (the reference's index_put / scatter_add backward is not), 5 launches
+//                       where the library merge sort of round 1 took 20.
 #include "common.hpp"
+#include "row_scatter.hpp"
 
 namespace {
 
@@ -92,93 +93,17 @@ __global__ __launch_bounds__(64 * WPB) void sdf_gather_kernel(
   }
 }
 
-// A wave takes 64 consecutive SORTED POSITIONS: each lane tests whether its position heads a run (first position,
-// or a key different from its predecessor's), and the wave's two 32-lane halves then work through the heads found
-// (ballot), one run each at a time: the half sums the run's source rows (first F of `ld` floats, times the pair
-// weight) in sorted order and stores the destination row once.  No list of run starts is built — a compaction
-// through one global cursor costs ~12 ns per returning atomic on this part (140 us for 0.5 M runs) — and no thread is
-// launched just to find out that it is not a head.  Pair weights are addressed by the ORIGINAL pair id
-// (`pair_sorted`).
-__global__ __launch_bounds__(256) void seg_sum_kernel(const unsigned* __restrict__ keys,
-                                                       const unsigned* __restrict__ pair_sorted, long long n,
-                                                       unsigned invalid_key, int F, int ld,
-                                                       const unsigned* __restrict__ src_row,
-                                                       const float* __restrict__ pair_w,
-                                                       const float* __restrict__ rows, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
-  const long long base = ((long long)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL;
-  const long long mine = base + lane;
-  // every lane resolves ITS position (key -> pair -> source row, weight) up front: one dependent-load chain for the
-  // whole wave instead of one per summed row; the run loops below fetch these through cross-lane reads
-  unsigned kme = invalid_key, srme = 0u;
-  float wme = 0.f;
-  bool head = false;
-  if (mine < n) {
-    kme = keys[mine];
-    head = kme != invalid_key && (mine == 0 || keys[mine - 1] != kme);
-    const unsigned pr = pair_sorted[mine];
-    srme = src_row[pr];
-    wme = pair_w[pr];
-  }
-  unsigned long long m = __ballot(head);
-  while (m) {
-    // the two lowest heads: half 0 takes the first, half 1 the second (if any)
-    const int h0 = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    int h1 = -1;
-    if (m) { h1 = __ffsll((long long)m) - 1; m &= m - 1; }
-    // run keys and lengths inside this wave's 64 positions (sorted: the lanes holding a key are contiguous from its
-    // head); everything wave-uniform, so that the cross-lane reads below run with all lanes enabled
-    const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)kme, h0);
-    const unsigned k1 = h1 >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)kme, h1) : invalid_key;
-    const int len0 = __popcll(__ballot(kme == k0)), len1 = h1 >= 0 ? __popcll(__ballot(kme == k1)) : 0;
-    const int hp = half == 0 ? h0 : (h1 < 0 ? h0 : h1);
-    const int len = half == 0 ? len0 : len1;
-    const bool active = half == 0 || h1 >= 0;
-    const unsigned k = half == 0 ? k0 : k1;
-    float a0 = 0.f, a1 = 0.f;
-    const int steps = len0 > len1 ? len0 : len1;
-    for (int t = 0; t < steps; ++t) {
-      const int q = min(hp + t, 63);
-      const size_t r = (size_t)(unsigned)__shfl((int)srme, q, 64) * ld;
-      const float w = __shfl(wme, q, 64);   // both cross-lane reads with every lane enabled
-      if (t < len) {
-        if (c < F) a0 = fmaf(w, rows[r + c], a0);
-        if (c + 32 < F) a1 = fmaf(w, rows[r + c + 32], a1);
-      }
-    }
-    if (active && hp + len == 64) {   // the run may continue in the next wave's positions
-      for (long long p = base + 64; p < n && keys[p] == k; ++p) {
-        const unsigned pr = pair_sorted[p];
-        const size_t r = (size_t)src_row[pr] * ld;
-        const float w = pair_w[pr];
-        if (c < F) a0 = fmaf(w, rows[r + c], a0);
-        if (c + 32 < F) a1 = fmaf(w, rows[r + c + 32], a1);
-      }
-    }
-    if (active) {
-      if (c < F) out[(size_t)k * F + c] = a0;
-      if (c + 32 < F) out[(size_t)k * F + c + 32] = a1;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void iota_kernel(unsigned* __restrict__ v, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = (unsigned)i;
-}
-
 struct Scratch {
   float *X, *gX, *gY, *pair_w;
-  unsigned *keys, *src_row, *pair_id, *keys_s, *pair_s, *run_start, *run_count;
+  unsigned *keys, *src_row;
   void* mlp;
-  char* temp;
-  size_t temp_bytes, total;
+  void* rows_plan;
+  size_t total;
 };
 
 size_t au(size_t v) { return (v + 255) / 256 * 256; }
 
-Scratch carve(void* base, int64_t B, int nnk, int F, int H) {
+Scratch carve(void* base, int64_t B, int nnk, int F, int H, int64_t rows) {
   Scratch s;
   const size_t n = (size_t)(B > 0 ? B : 1) * nnk;
   const int IN = F + 3;
@@ -191,26 +116,18 @@ Scratch carve(void* base, int64_t B, int nnk, int F, int H) {
   s.pair_w = (float*)take(n * sizeof(float));
   s.keys = (unsigned*)take(n * 4);
   s.src_row = (unsigned*)take(n * 4);
-  s.pair_id = (unsigned*)take(n * 4);
-  s.keys_s = (unsigned*)take(n * 4);
-  s.pair_s = (unsigned*)take(n * 4);
-  s.run_start = (unsigned*)take(n * 4);
-  s.run_count = (unsigned*)take(256);
   s.mlp = take(pings_mlp_backward_scratch_bytes(IN, H, 1));
-  size_t tb = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
-                                           (unsigned*)nullptr, (int)n, 0, 32);
-  s.temp_bytes = au(tb) + 256;
-  s.temp = take(s.temp_bytes);
+  s.rows_plan = take(pings_rows::carve(nullptr, (int64_t)n, rows).total);
   s.total = off;
   return s;
 }
 
 }  // namespace
 
-PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden) {
-  if (nn_k <= 0 || feat_dim <= 0 || hidden <= 0) return 0;
-  return carve(nullptr, B, nn_k, feat_dim, hidden).total;
+PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden,
+                                                  int64_t feature_rows) {
+  if (nn_k <= 0 || feat_dim <= 0 || hidden <= 0 || feature_rows <= 0) return 0;
+  return carve(nullptr, B, nn_k, feat_dim, hidden, feature_rows).total;
 }
 
 PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* features,
@@ -229,13 +146,9 @@ PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* feat
   PINGS_ARG_CHECK(!after_pgo || orientations, "after_pgo needs orientations");
   hipStream_t st = pings::as_stream(stream);
   const int F = dec->feat_dim, H = dec->hidden, IN = F + 3;
-  {
-    pings::prof::Scope ps("sdf_bwd_memset", st);
-    PINGS_HIP_CHECK(hipMemsetAsync(dL_dfeatures, 0, sizeof(float) * (size_t)feature_rows * F, st));
-  }
   PINGS_ARG_CHECK(B == 0 || (features && points && queries && idx && w && dL_dsdf), "null pointer");
   PINGS_ARG_CHECK((int64_t)B * nn_k < 0x7FFFFFFFLL, "too many (query, neighbour) pairs");
-  Scratch s = carve(scratch, B, nn_k, F, H);
+  Scratch s = carve(scratch, B, nn_k, F, H, feature_rows);
   const long long n = (long long)B * nn_k;               // (query, neighbour) pairs
   const long long nrows = dec->weighted_first ? B : n;    // MLP rows
   const unsigned invalid_key = (unsigned)feature_rows;    // sorts behind every real destination row
@@ -253,22 +166,10 @@ PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* feat
   if (int e = pings_mlp_backward(s.X, s.gY, nrows, IN, H, 1, dec->W1, dec->b1, dec->W2, s.mlp, s.gX, dL_dW1,
                                  dL_db1, dL_dW2, dL_db2, stream))
     return e;
-  if (B == 0) return PINGS_OK;
-  {
-    int bits = 1;
-    while ((1LL << bits) <= feature_rows) ++bits;  // keys are in [0, feature_rows]
-    size_t tb = s.temp_bytes;
-    {
-      pings::prof::Scope ps("sdf_bwd_sort", st);
-      hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.pair_id, n);
-      PINGS_LAUNCH_CHECK();
-      PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.temp, tb, s.keys, s.keys_s, s.pair_id, s.pair_s, (int)n,
-                                                         0, bits, st));
-    }
-    pings::prof::Scope ps("sdf_bwd_segsum", st);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.keys_s, s.pair_s, n,
-                       invalid_key, F, IN, s.src_row, s.pair_w, s.gX, dL_dfeatures);
-    PINGS_LAUNCH_CHECK();
-  }
+  // scatter-add of the feature-gradient columns of gX into the table; every row of dL_dfeatures is written
+  pings::prof::Scope ps("sdf_bwd_scatter", st);
+  pings_rows::Plan plan = pings_rows::carve(s.rows_plan, n, feature_rows);
+  if (int e = pings_rows::build(plan, s.keys, n, feature_rows, st)) return e;
+  if (int e = pings_rows::gather_sum(plan, feature_rows, F, s.gX, IN, s.src_row, s.pair_w, dL_dfeatures, st)) return e;
   return PINGS_OK;
 }

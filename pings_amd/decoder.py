@@ -8,8 +8,9 @@ independent).  `decoder` is the reference's `Decoder` object (or anything exposi
 
 HIP tensors go through `pings_mlp_forward/backward` (csrc/mlp.hip).  Host tensors raise: there is no
 CPU path (the CPU restatement used by the tests is the decoder's own `mlp_batch`, called from oracle/).
-Decoder shapes the kernel does not cover (more than one hidden level, leaky ReLU, no bias — none of the
-shipped configs, pings.py:147-172) run the module's own layers on the device.
+Decoder shapes the kernel does not cover (more than one hidden level, leaky ReLU, no bias, input > 64, output > 32
+or a hidden width outside {32, 64, 96, 128} — none of the shipped configs, pings.py:147-172) run the module's own
+torch layers ON THE DEVICE (`decoder.mlp_batch`): still no CPU path, but not a hand-written kernel either.
 """
 from __future__ import annotations
 
@@ -17,8 +18,13 @@ import torch
 
 
 def _supported(decoder) -> bool:
-    return len(decoder.layers) == 1 and not getattr(decoder, "use_leaky_relu", False) \
-        and decoder.layers[0].bias is not None and decoder.lout.bias is not None
+    if not (len(decoder.layers) == 1 and not getattr(decoder, "use_leaky_relu", False)
+            and decoder.layers[0].bias is not None and decoder.lout.bias is not None):
+        return False
+    from . import mlp as _mlp
+
+    W1, W2 = decoder.layers[0].weight, decoder.lout.weight
+    return _mlp.supported(int(W1.shape[1]), int(W1.shape[0]), int(W2.shape[0]))
 
 
 def mlp_batch(decoder, features: torch.Tensor) -> torch.Tensor:

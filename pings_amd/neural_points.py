@@ -4,8 +4,10 @@ Reference functions mirrored (model/neural_gaussians.py):
 * `radius_neighborhood_search(points, time_filtering)` :1061-1115  -> `radius_neighborhood_topk`
   (the HIP kernel returns the nn_k nearest directly instead of the [B,K] candidate matrices)
 * `query_feature(...)` :506-725 — same signature, same five return values, same side effects
-  (certainty accumulation :664-689); autograd-compatible including double backward, because
-  everything after the (non-differentiable) index search is expressed in torch ops on the device.
+  (certainty accumulation :664-689).  One HIP kernel forward (search + top-k + weights + gather), one
+  backward (d/dx through neighbour vectors and weights; feature gradients by a deterministic row
+  scatter-add) and one for the backward of the backward (`get_gradient(create_graph=True)`,
+  utils/tools.py:409-419): `pings_query_feature_{forward,backward,double_backward}`.
 * `Mapper.sdf` / `sdf_batch` (utils/mapper.py:2273-2318), tracker / mesher bulk queries
   -> `sdf_fused` (one kernel: search + gather + IDW + MLP [+ analytic gradient]).
 
@@ -41,10 +43,36 @@ class _CDecoder(C.Structure):
                 ("weighted_first", C.c_int32)]
 
 
+class _CQfTables(C.Structure):
+    _fields_ = [("geo_features", C.c_void_p), ("color_features", C.c_void_p), ("Fg", C.c_int32), ("Fc", C.c_int32),
+                ("points", C.c_void_p), ("orientations", C.c_void_p), ("certainties", C.c_void_p),
+                ("after_pgo", C.c_int32), ("weighted_first", C.c_int32)]
+
+
 def _declare(L):
     if getattr(L, "_knn_declared", False):
         return
     vp = C.c_void_p
+    L.pings_query_feature_forward.restype = C.c_int
+    L.pings_query_feature_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CQfTables), vp, C.c_int64] + [vp] * 12
+    L.pings_query_feature_scratch_bytes.restype = C.c_size_t
+    L.pings_query_feature_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int64]
+    L.pings_query_feature_backward.restype = C.c_int
+    L.pings_query_feature_backward.argtypes = [C.POINTER(_CQfTables), vp, vp, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp,
+                                               C.c_int64, vp, vp, vp, vp, vp]
+    L.pings_query_feature_double_backward.restype = C.c_int
+    L.pings_query_feature_double_backward.argtypes = [C.POINTER(_CQfTables), vp, vp, C.c_int64, C.c_int] + [vp] * 8 + \
+        [C.c_int64] + [vp] * 9
+    L.pings_rows_plan_bytes.restype = C.c_size_t
+    L.pings_rows_plan_bytes.argtypes = [C.c_int64, C.c_int64]
+    L.pings_rows_plan_build.restype = C.c_int
+    L.pings_rows_plan_build.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
+    L.pings_rows_plan_apply.restype = C.c_int
+    L.pings_rows_plan_apply.argtypes = [vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int32, vp, vp, vp]
+    L.pings_rows_scatter_add_scratch_bytes.restype = C.c_size_t
+    L.pings_rows_scatter_add_scratch_bytes.argtypes = [C.c_int64, C.c_int64]
+    L.pings_rows_scatter_add.restype = C.c_int
+    L.pings_rows_scatter_add.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, vp, vp, vp]
     L.pings_knn_search.restype = C.c_int
     L.pings_knn_search.argtypes = [C.POINTER(_CKnnMap), vp, C.c_int64, vp, vp, vp, vp, vp]
     L.pings_knn_compact_entries.restype = C.c_size_t
@@ -55,7 +83,7 @@ def _declare(L):
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
                                     C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_sdf_backward_scratch_bytes.restype = C.c_size_t
-    L.pings_sdf_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.pings_sdf_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]
     L.pings_sdf_backward.restype = C.c_int
     L.pings_sdf_backward.argtypes = [C.POINTER(_CDecoder), vp, C.c_int64, vp, vp, C.c_int32, vp, C.c_int64, C.c_int,
                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -167,102 +195,360 @@ def radius_neighborhood_topk(npm, points: torch.Tensor, time_filtering: bool = F
     return idx, d2, cnt
 
 
-def _apply_quaternion_rotation(quat, points):
-    # utils/tools.py:743-751
-    quat_w = quat[..., 0].unsqueeze(-1)
-    quat_xyz = -quat[..., 1:]
-    t = 2 * torch.linalg.cross(quat_xyz, points)
-    return points + quat_w * t + torch.linalg.cross(quat_xyz, t)
+def rows_scatter_add(dst_row: torch.Tensor, src: torch.Tensor, rows: int, w: torch.Tensor = None,
+                     src_row: torch.Tensor = None, F: int = None) -> torch.Tensor:
+    """out[r] = sum over pairs p with dst_row[p] == r (ascending p) of w[p] * src[src_row[p], :F]; [rows, F], bitwise
+    reproducible (`pings_rows_scatter_add`: the backward of a row gather without float atomics)."""
+    L = _L()
+    src2 = src.reshape(-1, src.shape[-1]).contiguous()
+    F = int(src2.shape[1] if F is None else F)
+    dst = dst_row.reshape(-1).to(torch.int64).contiguous()
+    n = dst.shape[0]
+    out = torch.empty(rows, F, dtype=torch.float32, device=src.device)
+    scratch = torch.empty(L.pings_rows_scatter_add_scratch_bytes(n, rows), dtype=torch.uint8, device=src.device)
+    wv = w.reshape(-1).to(torch.float32).contiguous() if w is not None else None
+    sr = src_row.reshape(-1).to(torch.int64).contiguous() if src_row is not None else None
+    _lib.check(L.pings_rows_scatter_add(_lib.ptr(dst), n, _lib.ptr(src2), int(src2.shape[1]), F, _lib.ptr(wv),
+                                        _lib.ptr(sr), rows, _lib.ptr(scratch), _lib.ptr(out),
+                                        _lib.stream_ptr(src.device)), "pings_rows_scatter_add")
+    return out
+
+
+class _QfState:
+    """What the backward kernels need besides the differentiable inputs (kept alive by the autograd graph)."""
+    __slots__ = ("tables", "keep", "gpoints", "idx", "gidx", "nn_k", "rows", "B", "Fg", "Fc", "weighted_first",
+                 "has_geo", "has_color", "geo_buf", "col_buf", "plan")
+
+
+def _qf_tables(st: _QfState, geo: torch.Tensor, col: torch.Tensor) -> _CQfTables:
+    """C struct for the CURRENT values of the feature tables (the double backward of weighted_first reads them)."""
+    t = st.tables
+    return _CQfTables(_lib.ptr(geo) if st.has_geo else None, _lib.ptr(col) if st.has_color else None,
+                      st.Fg if st.has_geo else 0, st.Fc if st.has_color else 0, t["points"].data_ptr(),
+                      t["quat"].data_ptr() if t["quat"] is not None else None,
+                      t["cert"].data_ptr() if t["cert"] is not None else None, int(t["after_pgo"]),
+                      int(st.weighted_first))
+
+
+def _c32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _qf_forward(x, geo_tab, col_tab, npm, opts, want_n: bool):
+    """Launches `pings_query_feature_forward`; returns (state, geo, colour, w [B,k], n [B,k,3] | None, cnt, cert)."""
+    L = _L()
+    (query_ts, accumulate_stability, query_locally, query_geo, query_color, use_meas, use_valid) = opts
+    dev = x.device
+    q = _c32(x)
+    B = q.shape[0]
+    a = _MapArgs(npm, bool(npm.temporal_local_map_on and query_locally), use_meas, use_valid, query_locally)
+    nn_k = a.nn_k
+    cfg = getattr(npm, "config", None)
+    wf = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
+    pts = (npm.local_neural_points if query_locally else npm.neural_points).detach().contiguous()
+    quat = (npm.local_point_orientations if query_locally else npm.point_orientations)
+    quat = quat.detach().contiguous() if quat is not None else None
+    cert_tab = npm.local_point_certainties if query_locally else npm.point_certainties
+    has_geo = bool(query_geo) and geo_tab is not None
+    has_col = bool(query_color) and col_tab is not None
+    geo_c = _c32(geo_tab) if has_geo else None
+    col_c = _c32(col_tab) if has_col else None
+    st = _QfState()
+    st.tables = {"points": pts, "quat": quat, "cert": cert_tab.detach() if cert_tab is not None else None,
+                 "after_pgo": bool(npm.after_pgo)}
+    st.gpoints = npm.neural_points.detach().contiguous()
+    st.nn_k, st.B, st.weighted_first = nn_k, B, wf
+    st.has_geo, st.has_color = has_geo, has_col
+    st.Fg = int(geo_c.shape[1]) if has_geo else 0
+    st.Fc = int(col_c.shape[1]) if has_col else 0
+    st.rows = int((geo_c if has_geo else col_c).shape[0])
+    st.plan = None
+    if has_geo and has_col and geo_c.shape[0] != col_c.shape[0]:
+        raise ValueError("query_feature: geo and colour feature tables must have the same number of rows")
+    if cert_tab is not None and (not cert_tab.is_contiguous() or cert_tab.dtype != torch.float32):
+        raise _lib.PingsHipError("query_feature: certainty table must be contiguous float32 (updated in place)")
+    tabs = _qf_tables(st, geo_c, col_c)
+    f32 = dict(dtype=torch.float32, device=dev)
+    shape = (lambda F: (B, F + 3)) if wf else (lambda F: (B, nn_k, F + 3))
+    geo = torch.empty(shape(st.Fg), **f32) if has_geo else None
+    col = torch.empty(shape(st.Fc), **f32) if has_col else None
+    w = torch.empty(B, nn_k, **f32)
+    n = torch.empty(B, nn_k, 3, **f32) if want_n else None
+    idx = torch.empty(B, nn_k, dtype=torch.int64, device=dev)
+    gidx = torch.empty(B, nn_k, dtype=torch.int64, device=dev)
+    cnt = torch.empty(B, dtype=torch.int64, device=dev)
+    cert = torch.empty(B, **f32) if cert_tab is not None else None
+    acc = ts_tab = qts = None
+    if accumulate_stability and cert_tab is not None:       # :664-689, under no_grad in the reference
+        # the queried certainty (:691-695) is computed from the values gathered BEFORE the accumulation (:615-620), so
+        # the kernel adds into a zeroed delta while every wave reads the untouched table; one add folds it in afterwards
+        acc = torch.zeros_like(cert_tab)
+        if query_locally and query_ts is not None:
+            ts_tab = npm.local_point_ts_update
+            if ts_tab.dtype != torch.int32 or not ts_tab.is_contiguous():
+                raise TypeError("local_point_ts_update must be a contiguous int32 tensor (neural_gaussians.py:138)")
+            qts = query_ts.detach().to(torch.int32).contiguous()
+    _lib.check(L.pings_query_feature_forward(
+        C.byref(a.c), C.byref(tabs), _lib.ptr(q), B, _lib.ptr(geo), _lib.ptr(col), _lib.ptr(w), _lib.ptr(idx),
+        _lib.ptr(gidx), _lib.ptr(cnt), _lib.ptr(cert), _lib.ptr(acc), _lib.ptr(qts), _lib.ptr(ts_tab), _lib.ptr(n),
+        _lib.stream_ptr(dev)), "pings_query_feature_forward")
+    if acc is not None:
+        with torch.no_grad():
+            cert_tab.add_(acc)
+    st.idx, st.gidx = idx, gidx
+    st.geo_buf, st.col_buf = geo, col
+    st.keep = a      # the map tensors the C struct points at
+    return st, geo, col, w, n, cnt, cert
+
+
+# ---------------------------------------------------------------- weighted_first: one graph node
+class _QfBackward(torch.autograd.Function):
+    """The backward of `_QueryFeature` as a differentiable op of its own: (g_geo, g_color, g_w, x, geo table, colour
+    table) -> (g_x, g_geo_table, g_color_table).  Its backward is `pings_query_feature_double_backward`."""
+
+    @staticmethod
+    def forward(ctx, g_geo, g_col, g_w, x, geo_tab, col_tab, st: _QfState, need_geo, need_col):
+        L = _L()
+        dev = x.device
+        q = _c32(x)
+        gg, gc, gw = _c32(g_geo), _c32(g_col), _c32(g_w)
+        geo_c, col_c = _c32(geo_tab), _c32(col_tab)
+        tabs = _qf_tables(st, geo_c, col_c)
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_x = torch.empty(st.B, 3, **f32)
+        g_gt = torch.empty(st.rows, st.Fg, **f32) if (need_geo and st.has_geo) else None
+        g_ct = torch.empty(st.rows, st.Fc, **f32) if (need_col and st.has_color) else None
+        scratch = None
+        if g_gt is not None or g_ct is not None:
+            scratch = torch.empty(L.pings_query_feature_scratch_bytes(st.B, st.nn_k, st.rows), dtype=torch.uint8, device=dev)
+        _lib.check(L.pings_query_feature_backward(
+            C.byref(tabs), _lib.ptr(st.gpoints), _lib.ptr(q), st.B, st.nn_k, _lib.ptr(st.idx), _lib.ptr(st.gidx),
+            _lib.ptr(gg), _lib.ptr(gc), None, _lib.ptr(gw), st.rows, _lib.ptr(scratch), _lib.ptr(g_x), _lib.ptr(g_gt),
+            _lib.ptr(g_ct), _lib.stream_ptr(dev)), "pings_query_feature_backward")
+        ctx.st = st
+        ctx.save_for_backward(gg, gc, gw, q, geo_c, col_c)
+        ctx.set_materialize_grads(False)
+        return g_x, g_gt, g_ct
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg_x, gg_gt, gg_ct):
+        L = _L()
+        st = ctx.st
+        gg, gc, gw, q, geo_c, col_c = ctx.saved_tensors
+        dev = q.device
+        tabs = _qf_tables(st, geo_c, col_c)
+        f32 = dict(dtype=torch.float32, device=dev)
+        wf = st.weighted_first
+        d_gg = torch.empty_like(gg) if gg is not None else None
+        d_gc = torch.empty_like(gc) if gc is not None else None
+        d_gw = torch.empty(st.B, st.nn_k, **f32)
+        need = ctx.needs_input_grad
+        d_x = torch.empty(st.B, 3, **f32) if need[3] else None
+        d_gt = torch.empty(st.rows, st.Fg, **f32) if (wf and need[4] and st.has_geo) else None
+        d_ct = torch.empty(st.rows, st.Fc, **f32) if (wf and need[5] and st.has_color) else None
+        scratch = None
+        if d_gt is not None or d_ct is not None:
+            scratch = torch.empty(L.pings_query_feature_scratch_bytes(st.B, st.nn_k, st.rows), dtype=torch.uint8, device=dev)
+        _lib.check(L.pings_query_feature_double_backward(
+            C.byref(tabs), _lib.ptr(st.gpoints), _lib.ptr(q), st.B, st.nn_k, _lib.ptr(st.idx), _lib.ptr(st.gidx),
+            _lib.ptr(gg), _lib.ptr(gc), _lib.ptr(gw), _lib.ptr(_c32(gg_x)), _lib.ptr(_c32(gg_gt)), _lib.ptr(_c32(gg_ct)),
+            st.rows, _lib.ptr(scratch), _lib.ptr(d_gg), _lib.ptr(d_gc), None, _lib.ptr(d_gw), _lib.ptr(d_x),
+            _lib.ptr(d_gt), _lib.ptr(d_ct), _lib.stream_ptr(dev)), "pings_query_feature_double_backward")
+        return d_gg, d_gc, (d_gw if gw is not None else None), d_x, d_gt, d_ct, None, None, None
+
+
+class _QueryFeature(torch.autograd.Function):
+    """weighted_first mode (:701-705): the outputs mix tables and geometry (sum_k w_k [f_k, n_k]), one graph node."""
+
+    @staticmethod
+    def forward(ctx, x, geo_tab, col_tab, npm, opts):
+        st, geo, col, w, _, cnt, cert = _qf_forward(x, geo_tab, col_tab, npm, opts, want_n=False)
+        ctx.st = st
+        ctx.save_for_backward(x, geo_tab if st.has_geo else None, col_tab if st.has_color else None)
+        ctx.mark_non_differentiable(cnt)
+        if cert is not None:
+            ctx.mark_non_differentiable(cert)
+        ctx.set_materialize_grads(False)
+        return geo, col, w.unsqueeze(-1), cnt, cert
+
+    @staticmethod
+    def backward(ctx, g_geo, g_col, g_w, _g_cnt, _g_cert):
+        x, geo_tab, col_tab = ctx.saved_tensors
+        st = ctx.st
+        need = ctx.needs_input_grad
+        if g_w is not None:
+            g_w = g_w.reshape(st.B, st.nn_k)
+        g_x, g_gt, g_ct = _QfBackward.apply(g_geo, g_col, g_w, x, geo_tab, col_tab, st, bool(need[1]), bool(need[2]))
+        return (g_x if need[0] else None), g_gt, g_ct, None, None
+
+
+# ---------------------------------------------------------------- per-neighbour mode: table path and query path apart
+# The outputs are [feature rows | neighbour vector] per (query, neighbour): the feature columns depend only on the
+# tables, the vector and the weights only on the query.  Each gets its own graph node, so that
+# `get_gradient(x, sdf)` (utils/tools.py:409-419) runs the cheap geometry backward alone and the table scatter only
+# runs when a table gradient is actually asked for (autograd cannot tell a monolithic Function which inputs a
+# particular backward call wants).  The forward kernel has already written both parts interleaved into one buffer;
+# `_QfInterleave` hands that buffer out without a copy.
+class _QfGeomBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_n, g_w, x, st: _QfState):
+        L = _L()
+        dev = x.device
+        q = _c32(x)
+        gn, gw = _c32(g_n), _c32(g_w)
+        if gn is None:
+            gn = torch.zeros(st.B, st.nn_k, 3, dtype=torch.float32, device=dev)
+        tabs = _qf_tables(st, None, None) if False else _CQfTables(
+            None, None, 0, 0, st.tables["points"].data_ptr(),
+            st.tables["quat"].data_ptr() if st.tables["quat"] is not None else None, None,
+            int(st.tables["after_pgo"]), 0)
+        g_x = torch.empty(st.B, 3, dtype=torch.float32, device=dev)
+        _lib.check(L.pings_query_feature_backward(
+            C.byref(tabs), _lib.ptr(st.gpoints), _lib.ptr(q), st.B, st.nn_k, _lib.ptr(st.idx), _lib.ptr(st.gidx),
+            None, None, _lib.ptr(gn), _lib.ptr(gw), st.rows, None, _lib.ptr(g_x), None, None, _lib.stream_ptr(dev)),
+            "pings_query_feature_backward")
+        ctx.st = st
+        ctx.tabs_args = None
+        ctx.save_for_backward(gn, gw, q)
+        ctx.set_materialize_grads(False)
+        return g_x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg_x):
+        L = _L()
+        st = ctx.st
+        gn, gw, q = ctx.saved_tensors
+        dev = q.device
+        if gg_x is None:
+            return None, None, None, None
+        tabs = _CQfTables(None, None, 0, 0, st.tables["points"].data_ptr(),
+                          st.tables["quat"].data_ptr() if st.tables["quat"] is not None else None, None,
+                          int(st.tables["after_pgo"]), 0)
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_gn = torch.empty(st.B, st.nn_k, 3, **f32)
+        d_gw = torch.empty(st.B, st.nn_k, **f32)
+        d_x = torch.empty(st.B, 3, **f32) if ctx.needs_input_grad[2] else None
+        _lib.check(L.pings_query_feature_double_backward(
+            C.byref(tabs), _lib.ptr(st.gpoints), _lib.ptr(q), st.B, st.nn_k, _lib.ptr(st.idx), _lib.ptr(st.gidx),
+            None, None, _lib.ptr(gw), _lib.ptr(_c32(gg_x)), None, None, st.rows, None, None, None, _lib.ptr(d_gn),
+            _lib.ptr(d_gw), _lib.ptr(d_x), None, None, _lib.stream_ptr(dev)), "pings_query_feature_double_backward")
+        return d_gn, (d_gw if gw is not None else None), d_x, None
+
+
+class _QfGeom(torch.autograd.Function):
+    """x -> (neighbour vectors n [B,k,3], weights w [B,k,1], nn_counts, certainty); launches the forward kernel, which
+    also fills the interleaved output buffers kept in the state."""
+
+    @staticmethod
+    def forward(ctx, x, geo_tab, col_tab, npm, opts, box):
+        st, geo, col, w, n, cnt, cert = _qf_forward(x, geo_tab, col_tab, npm, opts, want_n=True)
+        box.append(st)
+        ctx.st = st
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(cnt)
+        if cert is not None:
+            ctx.mark_non_differentiable(cert)
+        ctx.set_materialize_grads(False)
+        return n, w.unsqueeze(-1), cnt, cert
+
+    @staticmethod
+    def backward(ctx, g_n, g_w, _g_cnt, _g_cert):
+        (x,) = ctx.saved_tensors
+        st = ctx.st
+        if g_n is None and g_w is None:
+            return None, None, None, None, None, None
+        if g_w is not None:
+            g_w = g_w.reshape(st.B, st.nn_k)
+        return _QfGeomBackward.apply(g_n, g_w, x, st), None, None, None, None, None
+
+
+class _QfTable(torch.autograd.Function):
+    """feature table -> the feature columns of the interleaved output (a view of the buffer the forward kernel filled);
+    backward: deterministic row scatter-add of the upstream rows (`pings_rows_plan_build` once per batch, `_apply`
+    per table), reading the upstream gradient in place through its row stride."""
+
+    @staticmethod
+    def forward(ctx, tab, st: _QfState, which: int):
+        ctx.st, ctx.which = st, which
+        buf, F = (st.col_buf, st.Fc) if which else (st.geo_buf, st.Fg)
+        return buf[..., :F]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        L = _L()
+        st = ctx.st
+        F = st.Fc if ctx.which else st.Fg
+        dev = g.device
+        n_pairs = st.B * st.nn_k
+        if st.plan is None:
+            plan = torch.empty(L.pings_rows_plan_bytes(n_pairs, st.rows), dtype=torch.uint8, device=dev)
+            _lib.check(L.pings_rows_plan_build(_lib.ptr(st.idx), n_pairs, st.rows, _lib.ptr(plan), _lib.stream_ptr(dev)),
+                       "pings_rows_plan_build")
+            st.plan = plan
+        g = g.detach()
+        if g.dtype != torch.float32:
+            g = g.to(torch.float32)
+        # usually a strided view [B, k, F] of the contiguous [B, k, F+3] upstream gradient: read it where it lies
+        ld = g.stride(1) if g.dim() == 3 else 0
+        if not (g.dim() == 3 and g.stride(2) == 1 and g.stride(0) == st.nn_k * ld and ld >= F):
+            g = g.reshape(st.B, st.nn_k, F).contiguous()
+            ld = F
+        out = torch.empty(st.rows, F, dtype=torch.float32, device=dev)
+        _lib.check(L.pings_rows_plan_apply(_lib.ptr(st.plan), n_pairs, st.rows, g.data_ptr(), ld, F, None,
+                                           _lib.ptr(out), _lib.stream_ptr(dev)), "pings_rows_plan_apply")
+        return out, None, None
+
+
+class _QfInterleave(torch.autograd.Function):
+    """(feature columns, neighbour vectors) -> the [B, k, F+3] rows: zero-copy, the forward kernel wrote them
+    interleaved already; backward = the two column slices of the upstream gradient (views; differentiable)."""
+
+    @staticmethod
+    def forward(ctx, feat, n, buf):
+        ctx.F = feat.shape[-1]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        return g[..., :ctx.F], g[..., ctx.F:], None
 
 
 def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = None,
                   accumulate_stability: bool = True, query_locally: bool = True,
                   query_geo_feature: bool = True, query_color_feature: bool = False,
                   use_only_measured_points: bool = True, use_only_valid_points: bool = False):
-    """Drop-in for `NeuralPoints.query_feature` (model/neural_gaussians.py:506-725)."""
+    """Drop-in for `NeuralPoints.query_feature` (model/neural_gaussians.py:506-725): same arguments, same five
+    return values (geo [B,k,Fg+3] | [B,Fg+3], colour, weights [B,k,1], nn_counts [B], certainty [B]), same side
+    effects, differentiable twice w.r.t. the query, once w.r.t. the feature tables (twice in weighted_first mode)."""
     if not query_geo_feature and not query_color_feature:
         raise SystemExit("you need to at least query one kind of feature")  # :521-522
+    if not query_points.is_cuda:
+        raise _lib.PingsHipError("query_feature runs on the HIP device only (got a CPU tensor); there is no CPU "
+                                 "fallback — the CPU restatement is oracle/sdf_cpu.py (tests only)")
     cfg = self.config
-    nn_k = cfg.query_nn_k
-    batch_size = query_points.shape[0]
-    geo_features_vector = color_features_vector = None
-
-    idx, _, nn_counts, gidx = radius_neighborhood_topk(
-        self, query_points, time_filtering=self.temporal_local_map_on and query_locally,
-        use_only_measured_points=use_only_measured_points, use_only_valid_points=use_only_valid_points,
-        query_locally=query_locally, return_global=True)
-    valid_mask = idx >= 0
-    pts = self.local_neural_points if query_locally else self.neural_points
-    # squared distances stay in the autograd graph w.r.t. the query and are measured to the
-    # GLOBAL point the search found (:1098-1101), whatever global2local maps it to
-    diff = self.neural_points[gidx] - query_points.view(-1, 1, 3)
-    dists2 = torch.sum(diff ** 2, dim=-1)
-    dists2 = torch.where(valid_mask, dists2, torch.full_like(dists2, 9e3))
-
-    feats = self.local_geo_features if query_locally else self.geo_features
-    cfeats = self.local_color_features if query_locally else self.color_features
-    if query_geo_feature:
-        geo_features = torch.zeros(batch_size, nn_k, self.geo_feature_dim, device=query_points.device,
-                                   dtype=self.dtype)
-        geo_features[valid_mask] = feats[idx[valid_mask]]
-        if cfg.layer_norm_on:
-            geo_features = torch.nn.functional.layer_norm(geo_features, [self.geo_feature_dim])
-    if query_color_feature and cfeats is not None:
-        color_features = torch.zeros(batch_size, nn_k, self.color_feature_dim, device=query_points.device,
-                                     dtype=self.dtype)
-        color_features[valid_mask] = cfeats[idx[valid_mask]]
-        if cfg.layer_norm_on:
-            color_features = torch.nn.functional.layer_norm(color_features, [self.color_feature_dim])
-
-    N, K = valid_mask.shape
-    if query_locally:
-        certainty = self.local_point_certainties[idx]
-        quat = self.local_point_orientations[idx]
-    else:
-        certainty = self.point_certainties[idx]
-        quat = self.point_orientations[idx]
-    neighb_vector = query_points.view(-1, 1, 3) - pts[idx]
-    if self.after_pgo:
-        neighb_vector = _apply_quaternion_rotation(quat, neighb_vector)
-    neighb_vector = torch.where(valid_mask.unsqueeze(-1), neighb_vector, torch.zeros_like(neighb_vector))
-
-    if query_geo_feature:
-        geo_features_vector = torch.cat((geo_features, neighb_vector), dim=2)
-    if query_color_feature and cfeats is not None:
-        color_features_vector = torch.cat((color_features, neighb_vector), dim=2)
-
-    eps = 1e-15
-    weight_vector = 1.0 / (dists2 + eps)
-    weight_vector = torch.where(valid_mask, weight_vector, torch.zeros_like(weight_vector))
-    weight_vector = torch.where((nn_counts == 0).unsqueeze(1), torch.full_like(weight_vector, eps), weight_vector)
-    weight_row_sums = torch.sum(weight_vector, dim=1).unsqueeze(1)
-    weight_vector = torch.div(weight_vector, weight_row_sums)
-    weight_vector = torch.where(valid_mask, weight_vector, torch.zeros_like(weight_vector))
-
-    with torch.no_grad():
-        if accumulate_stability:
-            sidx = torch.where(valid_mask, idx, torch.zeros_like(idx))
-            if query_locally:
-                self.local_point_certainties.scatter_add_(dim=0, index=sidx.flatten(),
-                                                          src=weight_vector.detach().flatten())
-                if query_ts is not None:
-                    idx_ts = query_ts.view(-1, 1).repeat(1, K)
-                    idx_ts[~valid_mask] = 0
-                    self.local_point_ts_update.scatter_reduce_(dim=0, index=sidx.flatten(), src=idx_ts.flatten(),
-                                                               reduce="amax", include_self=True)
-            else:
-                self.point_certainties.scatter_add_(dim=0, index=sidx.flatten(),
-                                                    src=weight_vector.detach().flatten())
-        certainty = torch.where(valid_mask, certainty, torch.zeros_like(certainty))
-        queried_certainty = torch.sum(certainty * weight_vector.detach(), dim=1)
-
-    weight_vector = weight_vector.unsqueeze(-1)
-    if cfg.weighted_first:
-        if query_geo_feature:
-            geo_features_vector = torch.sum(geo_features_vector * weight_vector, dim=1)
-        if query_color_feature and cfeats is not None:
-            color_features_vector = torch.sum(color_features_vector * weight_vector, dim=1)
-    return geo_features_vector, color_features_vector, weight_vector, nn_counts, queried_certainty
+    if getattr(cfg, "layer_norm_on", False):
+        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (no shipped config sets it, "
+                                  "utils/config.py:95)")
+    feats = (self.local_geo_features if query_locally else self.geo_features) if query_geo_feature else None
+    cfeats = (self.local_color_features if query_locally else self.color_features) if query_color_feature else None
+    opts = (query_ts, bool(accumulate_stability), bool(query_locally), bool(query_geo_feature),
+            bool(query_color_feature), bool(use_only_measured_points), bool(use_only_valid_points))
+    if bool(cfg.weighted_first):
+        return _QueryFeature.apply(query_points, feats, cfeats, self, opts)
+    box = []
+    n, w, cnt, cert = _QfGeom.apply(query_points, feats.detach() if feats is not None else None,
+                                    cfeats.detach() if cfeats is not None else None, self, opts, box)
+    st = box[0]
+    geo = _QfInterleave.apply(_QfTable.apply(feats, st, 0), n, st.geo_buf) if st.has_geo else None
+    col = _QfInterleave.apply(_QfTable.apply(cfeats, st, 1), n, st.col_buf) if st.has_color else None
+    return geo, col, w, cnt, cert
 
 
 def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certainty: bool = False,
@@ -279,6 +565,8 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     q = x.detach().to(torch.float32).contiguous()
     B = q.shape[0]
     cfg = getattr(npm, "config", None)
+    if cfg is not None and getattr(cfg, "layer_norm_on", False):
+        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
     weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
     a = _MapArgs(npm, bool(npm.temporal_local_map_on and query_locally), use_only_measured_points,
                  use_only_valid_points, query_locally)
@@ -364,7 +652,7 @@ class _SdfTrain(torch.autograd.Function):
         gF = torch.empty_like(f)
         gW1, gb1 = torch.empty(H, F + 3, **f32), torch.empty(H, **f32)
         gW2, gb2 = torch.empty(1, H, **f32), torch.empty(1, **f32)
-        scratch = torch.empty(L.pings_sdf_backward_scratch_bytes(B, nn_k, F, H), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(L.pings_sdf_backward_scratch_bytes(B, nn_k, F, H, f.shape[0]), dtype=torch.uint8, device=dev)
         st = L.pings_sdf_backward(C.byref(dec), _lib.ptr(f), f.shape[0], _lib.ptr(pts), _lib.ptr(quat), int(after_pgo),
                                   _lib.ptr(q), B, nn_k, _lib.ptr(idx), _lib.ptr(w), _lib.ptr(g), _lib.ptr(scratch),
                                   _lib.ptr(gF), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
@@ -381,6 +669,8 @@ def sdf_train(npm, decoder, x: torch.Tensor, query_locally: bool = True, use_onl
     (first order: use `query_feature` when the loss needs a gradient of the gradient, mapper.py:1448).
     Returns (sdf[B], nn_counts[B])."""
     cfg = getattr(npm, "config", None)
+    if cfg is not None and getattr(cfg, "layer_norm_on", False):
+        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
     weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
     if len(decoder.layers) != 1 or getattr(decoder, "use_leaky_relu", False):
         raise NotImplementedError("sdf_train supports one-hidden-level ReLU decoders (every shipped config)")

@@ -77,11 +77,14 @@ def hip_settings(sc, mode="surfel", front_only=True, scale_modifier=1.0, device=
 
 
 # ------------------------------------------------------------------ surface-like scenes at BASELINE.json's shapes
-def _surfels_on(parts, P, gen, device, smin, smax, omin):
-    """Surfels lying on planar patches: `parts` = list of (count, point sampler, normal)."""
+def _surfels_on(parts, P, gen, device, smin, smax, omin, rough=0.01):
+    """Surfels lying on planar patches: `parts` = list of (count, point sampler, normal); `rough` = standard deviation
+    (m) of the offset along the normal, the roughness a SLAM map of a real wall has (exactly planar walls put every
+    surfel of a fronto-parallel wall at ONE depth, a degenerate input kept as its own robustness test)."""
     r = lambda *s: torch.rand(*s, generator=gen, device=device)
-    means = torch.cat([f(n, r) for n, f, _ in parts]).contiguous()
+    means = torch.cat([f(n, r) for n, f, _ in parts])
     nrm = torch.cat([torch.tensor(nv, dtype=torch.float32, device=device).expand(n, 3) for n, _, nv in parts])
+    means = (means + rough * torch.randn(means.shape[0], 1, generator=gen, device=device) * nrm).contiguous()
     z = torch.tensor([0.0, 0.0, 1.0], device=device).expand_as(nrm)
     v = torch.linalg.cross(z, nrm)
     c = (z * nrm).sum(1, keepdim=True)
@@ -93,23 +96,23 @@ def _surfels_on(parts, P, gen, device, smin, smax, omin):
     return means, r(P, 3), omin + (1 - omin) * r(P, 1), scales.contiguous(), rot
 
 
-def street_scene(P, device="cuda", seed=0):
+def street_scene(P, device="cuda", seed=0, rough=0.01):
     """KITTI-like view (BASELINE.json config C3): ground plane, two facades and a far wall, surfels on the surfaces,
     camera at the origin looking down +z (y down).  Tile lists are long and uneven (the horizon), nothing saturates
     early — the opposite regime of the SURVEY §8d Metric-1 cloud."""
     g = torch.Generator(device=device).manual_seed(seed)
-    n = P // 4
+    n, nf = int(0.3 * P), int(0.05 * P)                 # ground 35 %, two facades 30 % each, far wall 5 %
     F = lambda v, k: torch.full((k,), v, device=device)
     parts = [
-        (n, lambda k, r: torch.stack([(r(k) - 0.5) * 20, F(1.6, k), 2 + 58 * r(k) ** 1.5], 1), [0.0, -1.0, 0.0]),
+        (P - 2 * n - nf, lambda k, r: torch.stack([(r(k) - 0.5) * 20, F(1.6, k), 2 + 58 * r(k) ** 1.5], 1), [0.0, -1.0, 0.0]),
         (n, lambda k, r: torch.stack([F(-8.0, k), 1.6 - 6 * r(k), 2 + 58 * r(k) ** 1.5], 1), [1.0, 0.0, 0.0]),
         (n, lambda k, r: torch.stack([F(8.0, k), 1.6 - 6 * r(k), 2 + 58 * r(k) ** 1.5], 1), [-1.0, 0.0, 0.0]),
-        (P - 3 * n, lambda k, r: torch.stack([(r(k) - 0.5) * 16, 1.6 - 6 * r(k), F(60.0, k)], 1), [0.0, 0.0, -1.0]),
+        (nf, lambda k, r: torch.stack([(r(k) - 0.5) * 16, 1.6 - 6 * r(k), F(60.0, k)], 1), [0.0, 0.0, -1.0]),
     ]
-    return _surfels_on(parts, P, g, device, 0.03, 0.25, 0.3)
+    return _surfels_on(parts, P, g, device, 0.03, 0.25, 0.3, rough)
 
 
-def room_scene(P, device="cuda", seed=0):
+def room_scene(P, device="cuda", seed=0, rough=0.005):
     """Replica-like indoor view (config C2): a 6 x 3 x 8 m room seen from inside (floor, ceiling, three walls)."""
     g = torch.Generator(device=device).manual_seed(seed)
     n = P // 5
@@ -121,7 +124,7 @@ def room_scene(P, device="cuda", seed=0):
         (n, lambda k, r: torch.stack([F(3.0, k), 1.4 - 3 * r(k), 0.4 + 6.6 * r(k)], 1), [-1.0, 0.0, 0.0]),
         (P - 4 * n, lambda k, r: torch.stack([(r(k) - 0.5) * 6, 1.4 - 3 * r(k), F(7.0, k)], 1), [0.0, 0.0, -1.0]),
     ]
-    return _surfels_on(parts, P, g, device, 0.01, 0.06, 0.3)
+    return _surfels_on(parts, P, g, device, 0.01, 0.06, 0.3, rough)
 
 
 def scene_as_dict(means, col, op, scales, rot, W, H, fx, T_cw=None):
