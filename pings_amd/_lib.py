@@ -12,7 +12,10 @@ from pathlib import Path
 import torch
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "lib" / "libpings_hip.so"
+# PINGS_HIP_LIB: another build of the same library (A/B timing of kernel variants; never set in production)
+import os as _os
+
+LIB_PATH = Path(_os.environ["PINGS_HIP_LIB"]) if _os.environ.get("PINGS_HIP_LIB") else PKG / "lib" / "libpings_hip.so"
 HEADER = PKG.parent / "include" / "pings_hip.h"
 
 _lib = None

@@ -86,22 +86,31 @@ __device__ inline float wave_reduce16(const float (&v)[16], int lane) {
   r += dpp_mov<0x124>(sel4<1>(t, m0, m1));  // row_ror:4
   r += dpp_mov<0x128>(sel4<2>(t, m0, m1));  // row_ror:8
   r += dpp_mov<0x12c>(sel4<3>(t, m0, m1));  // row_ror:12
-  r += __shfl_xor(r, 16, 64);
-  r += __shfl_xor(r, 32, 64);
+  // cross-row adds r[l] + r[l ^ 16], then + the same of l ^ 32, on the vector ALU: gfx950's v_permlane16_swap /
+  // v_permlane32_swap exchange rows / halves between two registers, no LDS round trip (a ds_bpermute costs ~64 cycles
+  // of latency, twice per record here).  Inline asm: this hipcc maps both results of the builtin to one register.
+  {
+    float a = r, b = r;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r = a + b;
+    a = r; b = r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r = a + b;
+  }
   return r;
 }
 
 // PPL = pixels per lane (same lane -> pixel map as blend_fwd_kernel): the 16 gradient terms of a
 // lane's PPL pixels are summed in registers before the wave reduction, which is the expensive part.
 template <int MODE, int PPL>
-__global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
+__global__ __launch_bounds__(BLOCK / PPL, PPL == 4 ? 3 : 4) void blend_bwd_kernel(
     BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const float* __restrict__ inst_w,
-    const uint32_t* __restrict__ cidx, float* __restrict__ rows) {
+    const uint32_t* __restrict__ cidx, float* __restrict__ rows, const uint32_t* __restrict__ tile_order) {
   constexpr int NT = BLOCK / PPL;
   constexpr int NWV = NT / 64;
   __shared__ float4 sA[BATCH], sB[BATCH], sC[BATCH], sD[BATCH];
@@ -113,25 +122,33 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
+  const int tile = (int)tile_order[blockIdx.x];   // longest-processing-time-first dispatch (raster_fwd.hip)
   const int tx = tile % p.gx, ty = tile / p.gx;
   // lane -> pixel map and per-wave culled record lists as in blend_fwd_kernel (8x8 quadrants)
-  constexpr int YS = 8;
-  const int pix_x = tx * TILE + (PPL == 1 ? 8 * (wave & 1) : 8 * wave) + (lane & 7);
+  // PPL 1: wave = 8x8 quadrant; PPL 2: wave = 8x16 column strip (k -> y half); PPL 4: ONE wave owns the 16x16 tile
+  // (k & 1 -> x half, k >> 1 -> y half): no second wave to wait for, and the per-record overhead (LDS record fetch,
+  // 16-value wave reduction) is paid once per 256 pixels
+  constexpr int NXH = PPL == 4 ? 2 : 1;   // x halves per lane
+  const int pix_x = tx * TILE + (PPL == 1 ? 8 * (wave & 1) : (PPL == 2 ? 8 * wave : 0)) + (lane & 7);
   const int pix_y0 = ty * TILE + (PPL == 1 ? 8 * (wave >> 1) : 0) + (lane >> 3);
   const float pixf_x = (float)pix_x, pixf_y0 = (float)pix_y0;
+  auto xoff = [](int k) { return PPL == 4 ? 8 * (k & 1) : 0; };
+  auto yoff = [](int k) { return PPL == 4 ? 8 * (k >> 1) : 8 * k; };
   const float tileX0 = (float)(tx * TILE), tileY0 = (float)(ty * TILE);
   const size_t HW = (size_t)p.W * p.H;
 
-  float rx = 0.f, ry[PPL];
+  float rxv[NXH], ry[PPL];
+#pragma unroll
+  for (int h = 0; h < NXH; ++h) rxv[h] = 0.f;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) ry[k] = 0.f;
   if (MODE == MODE_SURFEL) {
     const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
     const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
-    rx = (pixf_x - cxp) / p.fx;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)(YS * k)) - cyp) / p.fy;
+    for (int h = 0; h < NXH; ++h) rxv[h] = ((pixf_x + (float)(8 * h)) - cxp) / p.fx;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) ry[k] = ((pixf_y0 + (float)yoff(k)) - cyp) / p.fy;
   }
 
   const uint2 range = ranges[tile];
@@ -145,9 +162,9 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
     T[k] = 1.f;
     gC0[k] = gC1[k] = gC2[k] = gN0[k] = gN1[k] = gN2[k] = gD[k] = coefT[k] = 0.f;
     Bs[k] = 0.f;
-    const int pix_y = pix_y0 + YS * k;
-    if (pix_x < p.W && pix_y < p.H) {
-      const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+    const int pix_y = pix_y0 + yoff(k), pix_xk = pix_x + xoff(k);
+    if (pix_xk < p.W && pix_y < p.H) {
+      const size_t pix_id = (size_t)pix_y * p.W + pix_xk;
       last[k] = n_contrib[pix_id];
       const float T_final = final_T[pix_id];
       T[k] = T_final;
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
       }
 #pragma unroll
       for (int wv = 0; wv < NWV; ++wv) {
-        const uint32_t need = PPL == 1 ? (1u << wv) : ((1u << wv) | (4u << wv));
+        const uint32_t need = PPL == 1 ? (1u << wv) : (PPL == 2 ? ((1u << wv) | (4u << wv)) : 0xFu);
         const bool hit = (qm & need) != 0;
         const unsigned long long bal = __ballot(hit);
         if (hit)
@@ -229,30 +246,41 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
 
     // Record j-1 is read from LDS while j is processed; per-lane conditions are selects, the only
     // branches are workgroup- or wave-uniform.
+    // Two-deep software pipeline over the wave's list: the INDEX of record jj-2 and the RECORD jj-1 are fetched
+    // from LDS while record jj is processed, so neither LDS latency (list byte -> record address -> 64-B record)
+    // sits in an iteration's dependency chain.
     const int cnt = sNum[wave];
     int jcur = cnt > 0 ? (int)sList[wave][cnt - 1] : 0;
+    int jnext = cnt > 1 ? (int)sList[wave][cnt - 2] : 0;
     float4 a = sA[jcur], bq = sB[jcur], c = sC[jcur], nn = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_SURFEL) nn = sD[jcur];
     for (int jj = cnt - 1; jj >= 0; --jj) {
       const int j = jcur;
-      const int jn = (int)sList[wave][jj > 0 ? jj - 1 : 0];
+      const int jn = jnext;
+      const int jn2 = (int)sList[wave][jj > 1 ? jj - 2 : 0];
       const float4 a_n = sA[jn], b_n = sB[jn], c_n = sC[jn];
       float4 n_n = nn;
       if (MODE == MODE_SURFEL) n_n = sD[jn];
       const float4 ca = a, cb = bq, cc = c, cn = nn;
       a = a_n; bq = b_n; c = c_n; nn = n_n;
       jcur = jn;
+      jnext = jn2;
       const uint32_t idx = (uint32_t)(start + j);
-      const float dx = ca.x - pixf_x;
-      const float p0 = -0.5f * (cb.x * dx * dx);
-      const float pxy = cb.y * dx;
+      float dxv[NXH], p0v[NXH], pxyv[NXH];
+#pragma unroll
+      for (int h = 0; h < NXH; ++h) {
+        dxv[h] = ca.x - (pixf_x + (float)(8 * h));
+        p0v[h] = -0.5f * (cb.x * dxv[h] * dxv[h]);
+        pxyv[h] = cb.y * dxv[h];
+      }
       float Gs[PPL], raw[PPL], alpha[PPL], dyv[PPL];
       bool valid[PPL];
       bool any_v = false;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const float dy = ca.y - (pixf_y0 + (float)(YS * k));
+        const float dy = ca.y - (pixf_y0 + (float)yoff(k));
         dyv[k] = dy;
+        const float p0 = p0v[PPL == 4 ? (k & 1) : 0], pxy = pxyv[PPL == 4 ? (k & 1) : 0];
         const float power = (p0 - 0.5f * (cb.z * dy * dy)) - pxy * dy;
         Gs[k] = __expf(power);
         raw[k] = ca.z * Gs[k];
@@ -272,6 +300,7 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
         // the forward pass): let multiply-adds fuse here — fewer instructions, one rounding less per term
 #pragma clang fp contract(fast)
         const float dy = dyv[k];
+        const float dx = dxv[PPL == 4 ? (k & 1) : 0], rx = rxv[PPL == 4 ? (k & 1) : 0];
         const float one_m = 1.0f - alpha[k];
         const float inv_one_m = __builtin_amdgcn_rcpf(one_m);  // 1-ulp reciprocal: alpha <= 0.99
         const float Tn = T[k] * inv_one_m;
@@ -329,6 +358,8 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
         T[k] = valid[k] ? Tn : T[k];
       }
       const float tot = wave_reduce16(v, lane);
+      // (one-wave kernel, PPL 4: storing the 64-byte row straight to global memory from here instead of through the
+      // LDS batch below was measured 5 % SLOWER: a scattered 16-lane store per record in the hot loop)
       if (lane < 16)
         reinterpret_cast<float*>(&sG[wave][j][0])[((lane & 1) << 3) | ((lane & 2) << 1) | (lane >> 2)] = tot;
     }
@@ -362,6 +393,22 @@ __global__ __launch_bounds__(BLOCK / PPL, 4) void blend_bwd_kernel(
 // pixels.  Each lane stores its 64-byte row once per (instance, quadrant); rows of one Gaussian stay contiguous and
 // are summed by the same per-Gaussian kernels.  Waves never synchronise with each other; pixels that finished
 // before the chunk are skipped for the whole wave.  Bitwise reproducible (fixed pixel order per lane).
+// work estimate of a tile for the dispatch order: the largest n_contrib of its 256 pixels (one wave per tile)
+__global__ __launch_bounds__(64) void tile_max_contrib_kernel(int W, int H, int gx, const uint32_t* __restrict__ n_contrib,
+                                                              uint32_t* __restrict__ work) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const int tx = tile % gx, ty = tile / gx;
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int x = tx * TILE + (lane & 15), y = ty * TILE + 4 * r + (lane >> 4);
+    if (x < W && y < H) m = max(m, n_contrib[(size_t)y * W + x]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if (lane == 0) work[tile] = m;
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_f(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
@@ -401,13 +448,14 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    const uint8_t* __restrict__ qmask, const uint32_t* __restrict__ cidx, float* __restrict__ rows) {
+    const uint8_t* __restrict__ qmask, const uint32_t* __restrict__ cidx, float* __restrict__ rows,
+    const uint32_t* __restrict__ tile_order) {
   __shared__ float4 sPix[64][4];  // {T, R, last, coefT} {gC0, gC1, gC2, gD} {gN0, gN1, gN2, px} {py, rx, ry, -}
   __shared__ int sQe[128];        // queue of relevant list entries, back to front
   __shared__ uint32_t sQs[128];   // their instance slots
 
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tile = (int)tile_order[blockIdx.x >> 2], q = blockIdx.x & 3;
   const int tx = tile % p.gx, ty = tile / p.gx;
   const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
   const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
@@ -1017,30 +1065,40 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
     hipLaunchKernelGGL(pair_owner_kernel, gridP, block, 0, st, P, bw.pair_off, bw.pair_owner);
     PINGS_LAUNCH_CHECK();
   }
+  if (I > 0) {
+    // backward dispatch order: tiles by descending largest per-pixel contributor count (the records a tile walks)
+    pings::prof::Scope ps("tile_order", st);
+    hipLaunchKernelGGL(tile_max_contrib_kernel, dim3(num_tiles), dim3(64), 0, st, bp.W, bp.H, bp.gx, im.n_contrib,
+                       bs.tile_work);
+    PINGS_LAUNCH_CHECK();
+    if (int e = launch_tile_order(bs.tile_work, num_tiles, bs.tile_order + num_tiles, st)) return e;
+  }
   if (I > 0 && scan_mode) {
     pings::prof::Scope ps("blend_bwd", st);
     if (s->mode == PINGS_RASTER_SURFEL)
       hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_SURFEL>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
                          bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
-                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows);
+                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows, bs.tile_order + num_tiles);
     else
       hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_3DGS>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
                          bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
-                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows);
+                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows, bs.tile_order + num_tiles);
     PINGS_LAUNCH_CHECK();
   } else if (I > 0) {
     pings::prof::Scope ps("blend_bwd", st);
-    int ppl = footprint_class == 2 ? 2 : 1;
+    int ppl = footprint_class == 2 ? 4 : 1;   // class 2: one wave per tile, four pixels per lane (0.40 -> 0.35 ms on Metric-1 vs two)
     if (const char* e = getenv("PINGS_BLEND_BWD_PPL")) ppl = atoi(e);
 #define PINGS_BLEND_BWD(M, L)                                                                            \
   hipLaunchKernelGGL((blend_bwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, bp, bs.ranges,    \
                      bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor,     \
-                     dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx, bw.rows)
+                     dL_dnormal, dL_ddepth, dL_dalpha, bs.inst_w, bw.cidx, bw.rows, bs.tile_order + num_tiles)
     if (s->mode == PINGS_RASTER_SURFEL) {
       if (ppl == 1) PINGS_BLEND_BWD(MODE_SURFEL, 1);
+      else if (ppl == 4) PINGS_BLEND_BWD(MODE_SURFEL, 4);
       else PINGS_BLEND_BWD(MODE_SURFEL, 2);
     } else {
       if (ppl == 1) PINGS_BLEND_BWD(MODE_3DGS, 1);
+      else if (ppl == 4) PINGS_BLEND_BWD(MODE_3DGS, 4);
       else PINGS_BLEND_BWD(MODE_3DGS, 2);
     }
 #undef PINGS_BLEND_BWD

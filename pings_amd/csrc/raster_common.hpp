@@ -97,6 +97,9 @@ struct BinState {
   float* inst_wq;      // [I][4] per-(instance, quadrant) sums of the wave-per-quadrant forward kernel, folded into
   uint32_t* inst_cntq; //        inst_w / inst_cnt / inst_qmask by combine_quadrants_kernel
   uint32_t* inst_cnt;  // [I]   per-instance pixel count with transmittance > 0.5 (3DGS)
+  uint32_t* tile_order;  // [2][num_tiles] tiles by descending work: [0] by list length (forward), [1] by the largest
+                         // per-pixel contributor count (backward) — longest-processing-time-first dispatch order
+  uint32_t* tile_work;   // [num_tiles] scratch of the two orderings
   char* temp;
   size_t temp_bytes;
   size_t total;
@@ -109,6 +112,8 @@ struct ImageState {
 };
 
 GeomState carve_geom(void* blob, int P, int num_tiles);
+// tile_order[i] = i-th tile in descending `work` (ties in any order: scheduling only, results do not depend on it)
+int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st);
 int occlusion_buckets(int num_tiles);
 BinState carve_binning(void* blob, int64_t I, int num_tiles);
 ImageState carve_image(void* blob, int W, int H);

@@ -110,6 +110,8 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
   b.slot_val = c.take<uint32_t>(n);
+  b.tile_order = c.take<uint32_t>(2 * (size_t)num_tiles);
+  b.tile_work = c.take<uint32_t>((size_t)num_tiles);
   b.temp_bytes = sort_temp_bytes((int64_t)n);
   b.temp = c.take<char>(b.temp_bytes);
   b.total = c.off;
@@ -749,6 +751,49 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int nb,
       });
 }
 
+// ---------------------------------------------------------------- longest-processing-time-first tile dispatch
+// A tile's blend time is proportional to its list; the lists are very uneven (Metric-1: 0..374 blended records,
+// mean 127), and workgroups are dispatched in grid order: with tiles in image order the long ones that start late
+// run on an otherwise idle chip.  Dispatching tiles in descending work order fills the tail with short ones.
+// One workgroup: counting sort of the tiles by min(work / 16, 1023), descending.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ work, int num_tiles,
+                                                          uint32_t* __restrict__ order) {
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t base[1024];
+  const int tid = threadIdx.x;
+  hist[tid] = 0u;
+  __syncthreads();
+  for (int t = tid; t < num_tiles; t += 1024) atomicAdd(&hist[min(work[t] >> 4, 1023u)], 1u);
+  __syncthreads();
+  // exclusive scan over the bins in DESCENDING bin order (bin 1023 first); 1024 threads, one bin each
+  uint32_t v = hist[1023 - tid];
+  base[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = tid >= off ? base[tid - off] : 0u;
+    __syncthreads();
+    base[tid] += add;
+    __syncthreads();
+  }
+  const uint32_t excl = base[tid] - v;
+  __syncthreads();
+  hist[1023 - tid] = excl;   // hist[bin] = first output position of the bin
+  __syncthreads();
+  for (int t = tid; t < num_tiles; t += 1024) order[atomicAdd(&hist[min(work[t] >> 4, 1023u)], 1u)] = (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void range_len_kernel(const uint2* __restrict__ ranges, int num_tiles,
+                                                        uint32_t* __restrict__ work) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < num_tiles) work[t] = ranges[t].y - ranges[t].x;
+}
+
+int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, work, num_tiles, order);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const KeyT* __restrict__ key,
                                                            uint2* __restrict__ ranges) {
@@ -1035,7 +1080,7 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
-    uint32_t* __restrict__ inst_cntq) {
+    uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order) {
   __shared__ float4 sA[64], sB[64], sC[64], sD[64];
   __shared__ uint32_t sSlot[64];
   __shared__ int sE[64];
@@ -1043,7 +1088,7 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
   __shared__ uint32_t sCnt[64];
 
   const int lane = threadIdx.x;
-  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tile = (int)tile_order[blockIdx.x >> 2], q = blockIdx.x & 3;
   const int tx = tile % p.gx, ty = tile / p.gx;
   const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
   const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
@@ -1177,6 +1222,203 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
       out_depth[pix_id] = D / fmaxf(A, DEPTH_ALPHA_EPS);
     } else {
       out_depth[pix_id] = D;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward, one independent wave per 16x16 tile
+// Footprint class 2 (footprints of many tiles: almost every record of a tile's list reaches all four quadrants, so
+// sub-tile culling buys nothing).  Same window pipeline as the quadrant kernel, but the wave owns the whole tile with
+// FOUR pixels per lane (k & 1 -> x half, k >> 1 -> y half): the record fetch from LDS, the footprint test and the
+// wave reduction of the blend weights are paid once per 256 pixels instead of once per 64, and the per-instance sum
+// is final — no per-quadrant partials, no 16-byte-per-instance memset, no combine pass.  Pixel arithmetic is the
+// quadrant kernel's, op for op (images bit-identical); the per-instance weight sum adds the same terms in another
+// order.  inst_qmask is NOT produced: only the pixel-per-lane backward (which this class uses) may follow.
+template <int MODE>
+__global__ __launch_bounds__(64) void blend_fwd_tile_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
+    float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_w,
+    uint32_t* __restrict__ inst_cnt, const uint32_t* __restrict__ tile_order) {
+  constexpr int PPL = 4;
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
+  __shared__ uint32_t sSlot[64];
+  __shared__ int sE[64];
+  __shared__ float sW[64];
+  __shared__ uint32_t sCnt[64];
+
+  const int lane = threadIdx.x;
+  const int tile = (int)tile_order[blockIdx.x];
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const float qx0 = (float)(tx * TILE), qy0 = (float)(ty * TILE);
+  const size_t HW = (size_t)p.W * p.H;
+  int pix_x[2], pix_y[2];
+  float pixf_x[2], pixf_y[2], rx[2] = {0.f, 0.f}, ry[2] = {0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    pix_x[h] = tx * TILE + 8 * h + (lane & 7);
+    pix_y[h] = ty * TILE + 8 * h + (lane >> 3);
+    pixf_x[h] = (float)pix_x[h];
+    pixf_y[h] = (float)pix_y[h];
+  }
+  if (MODE == MODE_SURFEL) {
+    const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+    const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      rx[h] = (pixf_x[h] - cxp) / p.fx;
+      ry[h] = (pixf_y[h] - cyp) / p.fy;
+    }
+  }
+  const uint2 range = ranges[tile];
+  const int todo = (int)(range.y - range.x);
+  float T[PPL], C0[PPL], C1[PPL], C2[PPL], N0[PPL], N1[PPL], N2[PPL], D[PPL];
+  uint32_t last[PPL];
+  bool done[PPL], inside[PPL];
+  bool all_done_lane = true;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    T[k] = 1.0f;
+    C0[k] = C1[k] = C2[k] = N0[k] = N1[k] = N2[k] = D[k] = 0.f;
+    last[k] = 0;
+    inside[k] = pix_x[k & 1] < p.W && pix_y[k >> 1] < p.H;
+    done[k] = !inside[k];
+    all_done_lane = all_done_lane && done[k];
+  }
+
+  uint32_t f_slot = 0, f_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
+  bool f_ok = false;
+  auto fetch = [&](int base) {
+    const int e = base + lane;
+    f_ok = e < todo;
+    if (f_ok) {
+      f_slot = point_list[range.x + e];
+      f_g = gval[f_slot];
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+    }
+  };
+  if (todo > 0 && !__all(all_done_lane)) fetch(0);
+
+  for (int base = 0; base < todo; base += 64) {
+    if (__all(all_done_lane)) break;
+    const uint32_t slot = f_slot, g = f_g;
+    const float4 ra = f_a, rb = f_b;
+    const bool ok = f_ok;
+    if (base + 64 < todo) fetch(base + 64);               // in flight while this window is blended
+    bool rel = false;
+    if (ok) {
+      const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
+      rel = !footprint_misses_rect(ra.x, ra.y, rb.x, rb.y, rb.z, thr, qx0, qx0 + 15.f, qy0, qy0 + 15.f);
+    }
+    const unsigned long long bal = __ballot(rel);
+    const int n = __popcll(bal);
+    if (rel) {
+      const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      sA[at] = ra;
+      sB[at] = rb;
+      sC[at] = rec[4 * (size_t)g + 2];
+      if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+      sSlot[at] = slot;
+      sE[at] = base + lane;
+    }
+    sW[lane] = 0.f;
+    if (MODE == MODE_3DGS) sCnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+
+    for (int j = 0; j < n; ++j) {
+      const float4 a = sA[j], b = sB[j], c = sC[j];
+      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == MODE_SURFEL) nn = sD[j];
+      float dxv[2], p0v[2], pxyv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        dxv[h] = a.x - pixf_x[h];
+        p0v[h] = -0.5f * (b.x * dxv[h] * dxv[h]);
+        pxyv[h] = b.y * dxv[h];
+      }
+      float alpha[PPL], test_T[PPL];
+      bool contrib[PPL];
+      bool any_c = false;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float dy = a.y - pixf_y[k >> 1];
+        const float power = (p0v[k & 1] - 0.5f * (b.z * dy * dy)) - pxyv[k & 1] * dy;
+        alpha[k] = fminf(ALPHA_MAX, a.z * __expf(power));
+        const bool valid = !done[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+        test_T[k] = T[k] * (1.0f - alpha[k]);
+        const bool stop = valid && (test_T[k] < T_EPS);
+        contrib[k] = valid && !stop;
+        done[k] = done[k] || stop;
+        any_c = any_c || contrib[k];
+      }
+      if (__any(any_c)) {
+        float wsum = 0.f;
+        uint32_t touched = 0;
+        const uint32_t e1 = (uint32_t)(sE[j] + 1);
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+          const float w = contrib[k] ? alpha[k] * T[k] : 0.f;
+          C0[k] = fmaf(c.x, w, C0[k]);
+          C1[k] = fmaf(c.y, w, C1[k]);
+          C2[k] = fmaf(c.z, w, C2[k]);
+          if (MODE == MODE_SURFEL) {
+            const float den = (nn.x * rx[k & 1] + nn.y * ry[k >> 1]) + nn.z;
+            float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+            d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+            N0[k] = fmaf(nn.x, w, N0[k]);
+            N1[k] = fmaf(nn.y, w, N1[k]);
+            N2[k] = fmaf(nn.z, w, N2[k]);
+            D[k] = fmaf(d, w, D[k]);
+          } else {
+            D[k] = fmaf(a.w, w, D[k]);
+            touched += (contrib[k] && test_T[k] > 0.5f) ? 1u : 0u;
+          }
+          T[k] = contrib[k] ? test_T[k] : T[k];
+          last[k] = contrib[k] ? e1 : last[k];
+          wsum += w;
+        }
+        const float s = wave_reduce_sum_dpp(wsum);
+        if (lane == 63) sW[j] = s;
+        if (MODE == MODE_3DGS) {
+          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
+          if (lane == 63) sCnt[j] = cn;
+        }
+      }
+      all_done_lane = (done[0] && done[1]) && (done[2] && done[3]);
+      if (__all(all_done_lane)) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      const float w = sW[lane];
+      if (w != 0.f) {  // untouched entries stay at their memset zero
+        inst_w[sSlot[lane]] = w;
+        if (MODE == MODE_3DGS) inst_cnt[sSlot[lane]] = sCnt[lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    if (!inside[k]) continue;
+    const size_t pix_id = (size_t)pix_y[k >> 1] * p.W + pix_x[k & 1];
+    const float A = 1.0f - T[k];
+    final_T[pix_id] = T[k];
+    n_contrib[pix_id] = last[k];
+    out_color[pix_id] = C0[k] + T[k] * p.bg[0];
+    out_color[HW + pix_id] = C1[k] + T[k] * p.bg[1];
+    out_color[2 * HW + pix_id] = C2[k] + T[k] * p.bg[2];
+    out_alpha[pix_id] = A;
+    if (MODE == MODE_SURFEL) {
+      out_normal[pix_id] = N0[k];
+      out_normal[HW + pix_id] = N1[k];
+      out_normal[2 * HW + pix_id] = N2[k];
+      out_depth[pix_id] = D[k] / fmaxf(A, DEPTH_ALPHA_EPS);
+    } else {
+      out_depth[pix_id] = D[k];
     }
   }
 }
@@ -1497,13 +1739,21 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
     }
   }
   {
+    // forward dispatch order: tiles by descending list length
+    pings::prof::Scope ps_o("tile_order", st);
+    hipLaunchKernelGGL(range_len_kernel, dim3(pings::ceil_div(num_tiles, 256)), dim3(256), 0, st, bs.ranges, num_tiles,
+                       bs.tile_work);
+    PINGS_LAUNCH_CHECK();
+    if (int e = launch_tile_order(bs.tile_work, num_tiles, bs.tile_order, st)) return e;
+  }
+  {
   pings::prof::Scope ps_blend("blend_fwd", st);
   // the wave-per-quadrant kernel is the fastest forward on both footprint classes (Metric-1: 0.244 vs 0.265 ms for
   // the workgroup-per-tile kernel with two pixels per lane; street-like scene: 0.86 vs 1.31 ms with one);
   // PINGS_BLEND_PPL = 1 | 2 selects the workgroup-per-tile kernel with that many pixels per lane (A/B runs, tests)
   int ppl = 0;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
-  if (I > 0 && ppl != 0) {  // the workgroup-per-tile kernels accumulate into zeroed per-instance sums
+  if (I > 0 && (ppl == 1 || ppl == 2)) {  // the workgroup-per-tile kernels accumulate into zeroed per-instance sums
     PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
     PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));
     if (s->mode == PINGS_RASTER_3DGS)
@@ -1524,21 +1774,36 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
     if (I > 0 && M == MODE_3DGS) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cntq, 0, 16 * (size_t)I, st)); \
     hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(4 * num_tiles), dim3(64), 0, st, kp, bs.ranges, \
                        bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
-                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq);                            \
+                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order);             \
     if (I > 0)                                                                                         \
       hipLaunchKernelGGL((combine_quadrants_kernel<M>), dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), \
                          dim3(256), 0, st, I, reinterpret_cast<const float4*>(bs.inst_wq),              \
                          reinterpret_cast<const uint4*>(bs.inst_cntq), bs.inst_w, bs.inst_cnt, bs.inst_qmask); \
   } while (0)
+  // footprint class 2 with the pixel-per-lane backward to follow (no quadrant masks needed): wave per TILE, four pixels
+  // per lane (Metric-1: 0.245 -> see DESIGN); PINGS_BLEND_PPL=4 forces it, PINGS_BLEND_PPL=-1 forces the quadrant kernel
+  const bool tile_wave = (ppl == 4) || (ppl == 0 && footprint_class == 2 && !want_qmask);
+#define PINGS_BLEND_FWD_TILE(M)                                                                        \
+  do {                                                                                                 \
+    if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));     \
+    if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));                   \
+    if (I > 0 && M == MODE_3DGS) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st)); \
+    hipLaunchKernelGGL((blend_fwd_tile_kernel<M>), dim3(num_tiles), dim3(64), 0, st, kp, bs.ranges,     \
+                       bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
+                       im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt, bs.tile_order);               \
+  } while (0)
   if (s->mode == PINGS_RASTER_SURFEL) {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_SURFEL, 1);
     else if (ppl == 2) PINGS_BLEND_FWD(MODE_SURFEL, 2);
+    else if (tile_wave) PINGS_BLEND_FWD_TILE(MODE_SURFEL);
     else PINGS_BLEND_FWD_WAVE(MODE_SURFEL);
   } else {
     if (ppl == 1) PINGS_BLEND_FWD(MODE_3DGS, 1);
     else if (ppl == 2) PINGS_BLEND_FWD(MODE_3DGS, 2);
+    else if (tile_wave) PINGS_BLEND_FWD_TILE(MODE_3DGS);
     else PINGS_BLEND_FWD_WAVE(MODE_3DGS);
   }
+#undef PINGS_BLEND_FWD_TILE
 #undef PINGS_BLEND_FWD
 #undef PINGS_BLEND_FWD_WAVE
   PINGS_LAUNCH_CHECK();

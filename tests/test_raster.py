@@ -151,11 +151,12 @@ def _check_list_prefixes(pl, rg, nc, o, W, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("occlusion,fwd_kernel", [("1", "0"), ("0", "0"), ("1", "1"), ("1", "2")])
+@pytest.mark.parametrize("occlusion,fwd_kernel", [("1", "0"), ("0", "0"), ("1", "1"), ("1", "2"), ("1", "4"), ("1", "-1")])
 @pytest.mark.parametrize("mode,front_only,seed", CASES)
 @pytest.mark.parametrize("size", [(700, 112, 80), (1500, 200, 120), (40, 33, 17)])
 def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size, occlusion, fwd_kernel, monkeypatch):
-    """fwd_kernel: 0 = wave-per-quadrant (default), 1 / 2 = workgroup-per-tile with 1 / 2 pixels per lane."""
+    """fwd_kernel (PINGS_BLEND_PPL): 0 = by footprint class (wave per quadrant, or wave per tile with 4 pixels per lane
+    for class 2), -1 = wave per quadrant, 4 = wave per tile, 1 / 2 = workgroup per tile with 1 / 2 pixels per lane."""
     monkeypatch.setenv("PINGS_RASTER_OCCLUSION", occlusion)
     monkeypatch.setenv("PINGS_BLEND_PPL", fwd_kernel)
     P, W, H = size
@@ -265,16 +266,20 @@ def _assert_grad_gate(names, got, ref64, ref32, what, flips_allowed=False):
             assert eh[0] <= max(bound, 5e-4), (what, name, eh, eo)
         else:
             k = max(8, int(1e-3 * a.numel()))
-            assert _max_without_worst(a, b64, k) <= bound and eh[1] <= 1e-3, (what, name, eh, eo)
+            assert _max_without_worst(a, b64, k) <= bound and eh[1] <= max(1e-3, 2.0 * eo[1]), (what, name, eh, eo)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel"])
+@pytest.mark.parametrize("bwd_kernel", ["scan", "pixel", "pixel4", "pixel2"])
 @pytest.mark.parametrize("mode,front_only,seed", CASES + [("surfel", True, 31), ("3dgs", True, 32)])
 def test_gradients_match_fp64_oracle(mode, front_only, seed, bwd_kernel, monkeypatch):
-    """Both blend-backward kernels (Gaussian-per-lane wave scans / pixel-per-lane reduce) against the fp64 oracle:
-    1e-4 relative per gradient tensor, or 1.5x the fp32 oracle's own distance from the fp64 one where that is larger."""
-    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel)
+    """The blend-backward kernels (Gaussian-per-lane wave scans / pixel-per-lane reduce with 1, 2 or 4 pixels per lane;
+    the last one follows the wave-per-tile forward) against the fp64 oracle: 1e-4 relative per gradient tensor, or
+    1.5x the fp32 oracle's own distance from the fp64 one where that is larger."""
+    monkeypatch.setenv("PINGS_BLEND_BWD", bwd_kernel[:5])
+    if bwd_kernel[5:]:
+        monkeypatch.setenv("PINGS_BLEND_BWD_PPL", bwd_kernel[5:])
+        monkeypatch.setenv("PINGS_BLEND_PPL", "4" if bwd_kernel[5:] == "4" else "0")
     sc = make_scene(400, 80, 64, seed=seed, surfel=(mode == "surfel"))
     _, names, ref64, ups = _oracle_grads(sc, torch.float64, mode, front_only)
     _, _, ref32, _ = _oracle_grads(sc, torch.float32, mode, front_only)
