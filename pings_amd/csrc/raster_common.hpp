@@ -30,7 +30,7 @@ constexpr float T_EPS = 1e-4f;
 constexpr float DEPTH_ALPHA_EPS = 1e-10f;
 constexpr float DEN_EPS = 1e-6f;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
-constexpr int DS_NB = 1 << 18;        // depth-sort buckets
+constexpr int DS_NB = 1 << 20;        // depth-sort buckets (2^18 left ~1.5k surfels per bucket on a rough fronto-parallel wall at 60 m: 0.43 ms of ranking)
 constexpr uint32_t DS_LIMIT = 4096u;  // bucket population beyond which the library sort takes over
 constexpr int DS_SHARDS = 64;  // single-address atomics serialise at ~12 ns each on this part: spread them
 // header words: [0, 64) max key shards, [64, 128) max ~key shards, 128 kmin, 129 shift, 130 overflow flag
