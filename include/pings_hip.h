@@ -321,22 +321,38 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
                                 float* grad_x, int64_t* nn_counts, float* certainty,
-                                int64_t* idx_out, float* w_out, float* sdf_std, void* stream);
+                                int64_t* idx_out, float* w_out, float* sdf_std, int64_t* gidx_out,
+                                void* stream);
 /* idx_out[B,nn_k] / w_out[B,nn_k] (optional): the neighbours (in the index space of `features`) and
- * their normalised inverse-distance weights, kept for pings_sdf_backward.  sdf_std[B] (optional): spread of the
+ * their normalised inverse-distance weights, kept for pings_sdf_backward; gidx_out[B,nn_k] (optional): the same
+ * neighbours as rows of m->neural_points (what the weights were measured to), kept for pings_sdf_double_backward.  sdf_std[B] (optional): spread of the
  * per-neighbour predictions sqrt(sum_m w_m (s_m - sdf)^2), the tracker's validity filter
  * (utils/tracker.py:303-313,408); 0 in weighted_first mode. */
 
 /* First-order backward of the fused query w.r.t. the feature table and the decoder
  * (the training path of Mapper.sdf_mapping, utils/mapper.py:822-970: loss(sdf).backward()).
- *   dL_dfeatures[rows,F]  dense, zero where no query touched the row
+ *   dL_dfeatures[rows,F]  dense, every row written (zero where no query touched the row)
  *   dL_dW1[H,F+3], dL_db1[H], dL_dW2[H], dL_db2[1]
- * Deterministic: per-(query, neighbour) gradient rows are written once, grouped by destination row
- * (counting sort, pings_rows_scatter_add below) and summed in ascending pair order; decoder gradients
- * are per-workgroup partials summed in fixed order.
+ * One wave per query evaluates the decoder backward on the vector ALU (lane = hidden unit, weight-gradient rows
+ * in registers), the per-(query, neighbour) feature-gradient rows are grouped by destination row (counting sort,
+ * pings_rows_scatter_add below) and summed in ascending pair order; decoder gradients are per-workgroup partials
+ * summed in fixed order.  Bitwise reproducible.  hidden <= 64.
  * `scratch` needs pings_sdf_backward_scratch_bytes(B, nn_k, F, H, feature_rows) bytes. */
 PINGS_API size_t pings_sdf_backward_scratch_bytes(int64_t B, int nn_k, int feat_dim, int hidden,
                                                   int64_t feature_rows);
+/* Backward of the backward: the consistency / Eikonal losses differentiate g = dS/dx (returned by
+ * pings_sdf_forward as grad_x) once more (get_gradient(create_graph=True), utils/tools.py:409-419;
+ * utils/mapper.py:1445-1448).  Given v[B,3] = dL/dg (times the dL/dS the first backward was called with), the
+ * gradients of  sum_b <v_b, dS_b/dx>  w.r.t. the feature table and the decoder, same outputs, scratch and
+ * determinism as pings_sdf_backward.  `gidx` [B,nn_k] / `global_points`: the rows of the global point array the
+ * weights were measured to (pings_sdf_forward gidx_out; == idx / points for a global query).  The gradient w.r.t.
+ * the query itself (a third derivative) is not produced. */
+PINGS_API int pings_sdf_double_backward(const pings_sdf_decoder* dec, const float* features,
+                                        int64_t feature_rows, const float* points, const float* orientations,
+                                        const float* global_points, int32_t after_pgo, const float* queries,
+                                        int64_t B, int nn_k, const int64_t* idx, const int64_t* gidx,
+                                        const float* w, const float* v, void* scratch, float* d_features,
+                                        float* d_W1, float* d_b1, float* d_W2, float* d_b2, void* stream);
 PINGS_API int pings_sdf_backward(const pings_sdf_decoder* dec, const float* features,
                                  int64_t feature_rows, const float* points,
                                  const float* orientations, int32_t after_pgo, const float* queries,

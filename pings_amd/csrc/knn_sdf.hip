@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,
     long long B, float* __restrict__ sdf_out, float* __restrict__ grad_out,
     long long* __restrict__ cnt_out, float* __restrict__ cert_out, long long* __restrict__ idx_out,
-    float* __restrict__ w_out, float* __restrict__ std_out) {
+    float* __restrict__ w_out, float* __restrict__ std_out, long long* __restrict__ gidx_out) {
   __shared__ long long sIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ long long sGIdx[WAVES_PER_BLOCK][MAX_NNK];
   __shared__ float sD2[WAVES_PER_BLOCK][MAX_NNK];
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     if (lane < nnk) {
       sW[wave][lane] = wgt;
       if (idx_out) idx_out[q * nnk + lane] = my_idx;
+      if (gidx_out) gidx_out[q * nnk + lane] = my_idx >= 0 ? sGIdx[wave][lane] : -1;
       if (w_out) w_out[q * nnk + lane] = wgt;
       float vx = 0.f, vy = 0.f, vz = 0.f;
       if (my_idx >= 0) {
@@ -182,7 +183,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       for (int mm = 0; mm < nnk; ++mm) {
         float pre = b1;
 #pragma unroll
-        for (int i = 0; i < IN_PAD; ++i) pre = fmaf(w1[i], sIn[wave][mm][i], pre);
+        for (int i = 0; i < IN_PAD; i += 4) {   // the row is broadcast from LDS sixteen bytes at a time
+          const float4 t4 = *reinterpret_cast<const float4*>(&sIn[wave][mm][i]);
+          pre = fmaf(w1[i], t4.x, pre);
+          pre = fmaf(w1[i + 1], t4.y, pre);
+          pre = fmaf(w1[i + 2], t4.z, pre);
+          pre = fmaf(w1[i + 3], t4.w, pre);
+        }
         const float h = fmaxf(pre, 0.f);
         const float s_m = dec.sdf_scale * (b2 + wave_sum_all(lane < Hd ? w2 * h : 0.f));
         sS[wave][mm] = s_m;
@@ -289,7 +296,8 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
                                 const float* orientations, const float* certainties,
                                 int32_t after_pgo, const float* queries, int64_t B, float* sdf,
                                 float* grad_x, int64_t* nn_counts, float* certainty,
-                                int64_t* idx_out, float* w_out, float* sdf_std, void* stream) {
+                                int64_t* idx_out, float* w_out, float* sdf_std, int64_t* gidx_out,
+                                void* stream) {
   if (int e = check_map(m)) return e;
   PINGS_ARG_CHECK(dec && dec->W1 && dec->b1 && dec->W2 && dec->b2, "null decoder");
   PINGS_ARG_CHECK(dec->hidden > 0 && dec->hidden <= 64, "hidden must be in 1..64");
@@ -304,7 +312,8 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
 #define PINGS_SDF_LAUNCH(PAD)                                                                          \
   hipLaunchKernelGGL(sdf_forward_kernel<PAD>, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \
                      *dec, features, points, orientations, certainties, (int)after_pgo, queries,       \
-                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out, sdf_std)
+                     (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out, sdf_std, \
+                     (long long*)gidx_out)
   if (in_dim <= 12) PINGS_SDF_LAUNCH(12);
   else if (in_dim <= 36) PINGS_SDF_LAUNCH(36);
   else PINGS_SDF_LAUNCH(64);

@@ -81,7 +81,10 @@ def _declare(L):
     L.pings_knn_compact_build.argtypes = [vp, C.c_int64, vp, C.c_size_t, vp]
     L.pings_sdf_forward.restype = C.c_int
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
-                                    C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+                                    C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pings_sdf_double_backward.restype = C.c_int
+    L.pings_sdf_double_backward.argtypes = [C.POINTER(_CDecoder), vp, C.c_int64, vp, vp, vp, C.c_int32, vp, C.c_int64,
+                                            C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_sdf_backward_scratch_bytes.restype = C.c_size_t
     L.pings_sdf_backward_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]
     L.pings_sdf_backward.restype = C.c_int
@@ -595,7 +598,7 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     std = torch.empty(B, dtype=torch.float32, device=dev) if need_std else None
     st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(feats), _lib.ptr(pts), _lib.ptr(quat),
                              _lib.ptr(cert_tab), int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf),
-                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), None, None, _lib.ptr(std),
+                             _lib.ptr(grad), _lib.ptr(cnt), _lib.ptr(cert), None, None, _lib.ptr(std), None,
                              _lib.stream_ptr(dev))
     _lib.check(st, "pings_sdf_forward")
     if need_std:
@@ -603,8 +606,98 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     return sdf, grad, cnt, cert
 
 
+_SCRATCH_BYTES = {}
+
+
+def _sdf_scratch(L, B, nn_k, F, H, rows, dev):
+    key = (B, nn_k, F, H, rows)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
+        n = _SCRATCH_BYTES[key] = L.pings_sdf_backward_scratch_bytes(B, nn_k, F, H, rows)
+    return torch.empty(n, dtype=torch.uint8, device=dev)
+
+
+def _sdf_first_order(st, g_sdf):
+    """(g_x, gF, gW1, gb1, gW2, gb2) of the fused query for the upstream gradient g_sdf [B] (no autograd here)."""
+    L = _L()
+    q, f, W1c, b1c, W2c, b2c, idx, gidx, w, pts, quat, gpts, unit = st["saved"]
+    sdf_scale, weighted_first, after_pgo, nn_k = st["meta"]
+    B, F, H = q.shape[0], f.shape[1], W1c.shape[0]
+    dev = q.device
+    g = g_sdf.detach()
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        g = g.to(torch.float32).contiguous()
+    gF = gW1 = gb1 = gW2 = gb2 = None
+    if st["need_params"]:
+        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(H), int(F),
+                        float(sdf_scale), int(weighted_first))
+        gF = torch.empty_like(f)
+        flat = torch.empty(H * (F + 5) + 1, dtype=torch.float32, device=dev)      # one allocation for the decoder
+        gW1, gb1 = flat[:H * (F + 3)].view(H, F + 3), flat[H * (F + 3):H * (F + 4)]
+        gW2, gb2 = flat[H * (F + 4):H * (F + 5)].view(1, H), flat[H * (F + 5):]
+        scratch = _sdf_scratch(L, B, nn_k, F, H, f.shape[0], dev)
+        base = flat.data_ptr()
+        _lib.check(L.pings_sdf_backward(C.byref(dec), f.data_ptr(), f.shape[0], pts.data_ptr(), quat.data_ptr(),
+                                        int(after_pgo), q.data_ptr(), B, nn_k, idx.data_ptr(), w.data_ptr(), g.data_ptr(),
+                                        scratch.data_ptr(), gF.data_ptr(), base, base + 4 * H * (F + 3),
+                                        base + 4 * H * (F + 4), base + 4 * H * (F + 5), _lib.stream_ptr(dev)),
+                   "pings_sdf_backward")
+    gx = unit * g.unsqueeze(1) if unit is not None else None
+    return g, (gx, gF, gW1, gb1, gW2, gb2)
+
+
+class _SdfTrainBackward(torch.autograd.Function):
+    """The backward of `_SdfTrain` as a differentiable op: (g_sdf, x, feats, W1, b1, W2, b2) -> (g_x, g_feats, g_W1,
+    g_b1, g_W2, g_b2).  g_x = g_sdf * dS/dx uses the analytic gradient the forward kernel produced; the parameter
+    gradients come from `pings_sdf_backward`.  Its own backward (`pings_sdf_double_backward`) propagates a gradient
+    arriving at g_x — the Eikonal / consistency losses on dS/dx (utils/mapper.py:1445-1448) — to the features and the
+    decoder; gradients arriving at the parameter-gradient outputs (third-order use) are not supported.  Only entered
+    when the backward itself is being recorded (create_graph=True); a plain backward calls `_sdf_first_order`."""
+
+    @staticmethod
+    def forward(ctx, g_sdf, x, feats, W1, b1, W2, b2, st):
+        g, out = _sdf_first_order(st, g_sdf)
+        ctx.st = st
+        ctx.save_for_backward(g)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg_x, gg_F, gg_W1, gg_b1, gg_W2, gg_b2):
+        if any(t is not None for t in (gg_F, gg_W1, gg_b1, gg_W2, gg_b2)):
+            raise NotImplementedError("sdf_train: differentiating the PARAMETER gradients once more is not implemented")
+        if gg_x is None:
+            return (None,) * 8
+        L = _L()
+        st = ctx.st
+        (g,) = ctx.saved_tensors
+        q, f, W1c, b1c, W2c, b2c, idx, gidx, w, pts, quat, gpts, unit = st["saved"]
+        sdf_scale, weighted_first, after_pgo, nn_k = st["meta"]
+        B, F, H = q.shape[0], f.shape[1], W1c.shape[0]
+        dev = q.device
+        ggx = gg_x.detach().to(torch.float32).contiguous()
+        v = (ggx * g.unsqueeze(1)).contiguous()            # Phi = sum_b <v_b, dS_b/dx>
+        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(H), int(F),
+                        float(sdf_scale), int(weighted_first))
+        f32 = dict(dtype=torch.float32, device=dev)
+        dF = torch.empty_like(f)
+        dW1, db1 = torch.empty(H, F + 3, **f32), torch.empty(H, **f32)
+        dW2, db2 = torch.empty(1, H, **f32), torch.empty(1, **f32)
+        scratch = _sdf_scratch(L, B, nn_k, F, H, f.shape[0], dev)
+        _lib.check(L.pings_sdf_double_backward(
+            C.byref(dec), _lib.ptr(f), f.shape[0], _lib.ptr(pts), _lib.ptr(quat), _lib.ptr(gpts), int(after_pgo),
+            _lib.ptr(q), B, nn_k, _lib.ptr(idx), _lib.ptr(gidx), _lib.ptr(w), _lib.ptr(v), _lib.ptr(scratch),
+            _lib.ptr(dF), _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), _lib.stream_ptr(dev)),
+            "pings_sdf_double_backward")
+        d_g = (ggx * unit).sum(1) if unit is not None else None     # g_x is linear in g_sdf
+        # the gradient w.r.t. the query (a third derivative of S) is not produced: None
+        return d_g, None, dF, dW1, db1, dW2, db2, None
+
+
 class _SdfTrain(torch.autograd.Function):
-    """S(x) with a fused first-order backward to the feature table and the decoder (`pings_sdf_backward`)."""
+    """S(x) with fused first- and second-order backward to the feature table and the decoder
+    (`pings_sdf_forward` / `pings_sdf_backward` / `pings_sdf_double_backward`)."""
 
     @staticmethod
     def forward(ctx, x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, query_locally, use_meas, use_valid):
@@ -618,48 +711,37 @@ class _SdfTrain(torch.autograd.Function):
         F = f.shape[1]
         dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(W1c.shape[0]), int(F),
                         float(sdf_scale), int(weighted_first))
-        pts = (npm.local_neural_points if query_locally else npm.neural_points).contiguous()
-        quat = (npm.local_point_orientations if query_locally else npm.point_orientations).contiguous()
+        pts = (npm.local_neural_points if query_locally else npm.neural_points).detach().contiguous()
+        quat = (npm.local_point_orientations if query_locally else npm.point_orientations).detach().contiguous()
+        gpts = npm.neural_points.detach().contiguous()
         dev = q.device
         sdf = torch.empty(B, dtype=torch.float32, device=dev)
         cnt = torch.empty(B, dtype=torch.int64, device=dev)
         idx = torch.empty(B, a.nn_k, dtype=torch.int64, device=dev)
         w = torch.empty(B, a.nn_k, dtype=torch.float32, device=dev)
         need_gx = x.requires_grad
-        gx = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
+        gidx = torch.empty(B, a.nn_k, dtype=torch.int64, device=dev) if need_gx else None
+        unit = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
         st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(f), _lib.ptr(pts), _lib.ptr(quat), None,
-                                 int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf), _lib.ptr(gx), _lib.ptr(cnt),
-                                 None, _lib.ptr(idx), _lib.ptr(w), None, _lib.stream_ptr(dev))
+                                 int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf), _lib.ptr(unit), _lib.ptr(cnt),
+                                 None, _lib.ptr(idx), _lib.ptr(w), None, _lib.ptr(gidx), _lib.stream_ptr(dev))
         _lib.check(st, "pings_sdf_forward")
-        ctx.save_for_backward(q, f, W1c, b1c, W2c, b2c, idx, w, pts, quat)
-        ctx.gx = gx
-        ctx.meta = (float(sdf_scale), int(weighted_first), bool(npm.after_pgo), a.nn_k)
+        ctx.state = {"saved": (q, f, W1c, b1c, W2c, b2c, idx, gidx, w, pts, quat, gpts, unit),
+                     "meta": (float(sdf_scale), int(weighted_first), bool(npm.after_pgo), a.nn_k),
+                     "need_params": any(t.requires_grad for t in (feats, W1, b1, W2, b2)), "keep": a}
+        ctx.save_for_backward(x, feats, W1, b1, W2, b2)
         ctx.mark_non_differentiable(cnt)
         return sdf, cnt
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, _g_cnt):
-        L = _L()
-        q, f, W1c, b1c, W2c, b2c, idx, w, pts, quat = ctx.saved_tensors
-        sdf_scale, weighted_first, after_pgo, nn_k = ctx.meta
-        B, F, H = q.shape[0], f.shape[1], W1c.shape[0]
-        dev = q.device
-        g = g_sdf.detach().to(torch.float32).contiguous()
-        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(H), int(F),
-                        float(sdf_scale), int(weighted_first))
-        f32 = dict(dtype=torch.float32, device=dev)
-        gF = torch.empty_like(f)
-        gW1, gb1 = torch.empty(H, F + 3, **f32), torch.empty(H, **f32)
-        gW2, gb2 = torch.empty(1, H, **f32), torch.empty(1, **f32)
-        scratch = torch.empty(L.pings_sdf_backward_scratch_bytes(B, nn_k, F, H, f.shape[0]), dtype=torch.uint8, device=dev)
-        st = L.pings_sdf_backward(C.byref(dec), _lib.ptr(f), f.shape[0], _lib.ptr(pts), _lib.ptr(quat), int(after_pgo),
-                                  _lib.ptr(q), B, nn_k, _lib.ptr(idx), _lib.ptr(w), _lib.ptr(g), _lib.ptr(scratch),
-                                  _lib.ptr(gF), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW2), _lib.ptr(gb2),
-                                  _lib.stream_ptr(dev))
-        _lib.check(st, "pings_sdf_backward")
-        gx = ctx.gx * g.unsqueeze(1) if ctx.gx is not None else None
-        return gx, gF, gW1, gb1, gW2, gb2, None, None, None, None, None, None
+        x, feats, W1, b1, W2, b2 = ctx.saved_tensors
+        if g_sdf is None:
+            return (None,) * 12
+        if not torch.is_grad_enabled():           # plain backward: nothing will differentiate this call
+            return _sdf_first_order(ctx.state, g_sdf)[1] + (None,) * 6
+        out = _SdfTrainBackward.apply(g_sdf, x, feats, W1, b1, W2, b2, ctx.state)
+        return tuple(out) + (None,) * 6
 
 
 def sdf_train(npm, decoder, x: torch.Tensor, query_locally: bool = True, use_only_measured_points: bool = True,

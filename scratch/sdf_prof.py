@@ -1,6 +1,6 @@
 """Stage times of the SDF training paths (fused sdf_train; query_feature + torch MLP, first order and Eikonal)."""
 import sys, time, json
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import bench
 from pings_amd import neural_points as hnp

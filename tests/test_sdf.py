@@ -448,3 +448,65 @@ def test_rows_scatter_add_is_exact_and_reproducible():
     # no pairs at all: a table of zeros
     z = hnp.rows_scatter_add(torch.empty(0, dtype=torch.int64, device="cuda"), torch.empty(0, 8, device="cuda"), 10)
     assert z.shape == (10, 8) and float(z.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ fused Mapper.sdf: first and second order
+class _FakeMapper:
+    """The attributes `pings_amd.mapper_ops` reads from the reference's Mapper."""
+
+    def __init__(self, npm, dec):
+        from types import SimpleNamespace as NS
+
+        self.neural_points, self.sdf_mlp = npm, dec
+        self.config = NS(weighted_first=npm.weighted_first)
+        self.dtype, self.device = torch.float32, "cuda"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_fused_mapper_sdf_double_backward_matches_reference_golden(golden_dir, name):
+    """`Mapper.sdf` + `get_gradient(create_graph=True)` + backward (utils/mapper.py:1445-1448, the G3 vectors) through
+    the FUSED kernels: pings_sdf_forward -> pings_sdf_backward / pings_sdf_double_backward, no torch op in between."""
+    from types import SimpleNamespace as NS
+
+    from pings_amd import mapper_ops
+
+    st = load(golden_dir, name)
+    gpu = _gpu_map(st)
+    gpu.local_geo_features.requires_grad_(True)
+    t = lambda k: torch.nn.Parameter(T(st["dec." + k]).cuda())
+    d = NS(layers=[NS(weight=t("layers.0.weight"), bias=t("layers.0.bias"))],
+           lout=NS(weight=t("lout.weight"), bias=t("lout.bias")), sdf_scale=float(st["sdf_scale"]), use_leaky_relu=False)
+    m = _FakeMapper(gpu, d)
+    params = [gpu.local_geo_features, d.layers[0].weight, d.layers[0].bias, d.lout.weight, d.lout.bias]
+    outs = []
+    for _ in range(2):
+        x = T(st["x"]).cuda().requires_grad_(True)
+        s, _, valid = mapper_ops.sdf(m, x, min_nn_count=1)
+        g = sdf_cpu.get_gradient(x, s)
+        loss = ((g.norm(dim=-1) - 1.0) ** 2).mean() + s.abs().mean()
+        outs.append(torch.autograd.grad(loss, params))
+    assert rel_err(s, T(st["g3_sdf"])) <= 1e-4
+    assert rel_err(g, T(st["g3_grad_x"])) <= 1e-4
+    assert abs(loss.item() - float(st["g3_loss"])) <= 1e-4 * max(1.0, abs(float(st["g3_loss"])))
+    names = ["g3_dfeat", "g3_d.layers.0.weight", "g3_d.layers.0.bias", "g3_d.lout.weight", "g3_d.lout.bias"]
+    for a, k in zip(outs[0], names):
+        assert rel_err(a.reshape(T(st[k]).shape), T(st[k])) <= 1e-4, (k, rel_err(a.reshape(T(st[k]).shape), T(st[k])))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                                   # bitwise reproducible
+    # inference forms agree with the training form
+    with torch.no_grad():
+        s2, std, v2 = mapper_ops.sdf(m, T(st["x"]).cuda(), get_std=True)
+        s3, _, v3 = mapper_ops.sdf_batch(m, T(st["x"]).cuda(), 1000)
+    assert torch.equal(s2, s.detach()) and torch.equal(s3, s2) and torch.equal(v2, valid) and torch.equal(v3, valid)
+    # numerical gradient: six shifted queries in one launch, differentiable to the parameters
+    xq = T(st["x"]).cuda()[:512]
+    gn = mapper_ops.get_numerical_gradient(m, xq, eps=0.05)
+    cpu = sdf_cpu.NeuralPointMap(st)
+    dec_c = sdf_cpu.MLP.from_state(st)
+    e = torch.eye(3) * 0.05
+    xc = T(st["x"])[:512]
+    ref = torch.cat([(sdf_cpu.mapper_sdf(cpu, dec_c, xc + e[i])[0] - sdf_cpu.mapper_sdf(cpu, dec_c, xc - e[i])[0])[:, None] / 0.1
+                     for i in range(3)], 1)
+    assert rel_err(gn, ref) <= 1e-3          # difference quotient of fp32 values: cancellation
+    torch.autograd.grad(gn.square().sum(), params)
