@@ -380,6 +380,35 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
                                  void* scratch, float* dL_dx, float* dL_dW1, float* dL_db1,
                                  float* dL_dW2, float* dL_db2, void* stream);
 
+/* Several decoders over the SAME N rows in one launch each way (blockIdx.y = decoder): the five spawn decoders of
+ * a view (gaussian_renderer/__init__.py:605-716; hidden 128, IN <= 32 — pings.py:156-160).  Results are bitwise
+ * those of pings_mlp_forward / pings_mlp_backward called per decoder.  Unused directions leave their pointers NULL
+ * (dL_dx may be NULL in the backward).  scratch: pings_mlp_backward_grouped_scratch_bytes(jobs, njobs). */
+typedef struct pings_mlp_job {
+  const float* x;                    /* [N, IN]                                   */
+  int32_t IN, OUT;                   /* IN <= 32, OUT <= 32, hidden width = 128   */
+  const float *W1, *b1, *W2, *b2;    /* [128, IN], [128], [OUT, 128], [OUT]       */
+  float* y;                          /* forward:  [N, OUT]                        */
+  const float* dL_dy;                /* backward: [N, OUT]                        */
+  float* dL_dx;                      /*           [N, IN] or NULL                 */
+  float *dL_dW1, *dL_db1, *dL_dW2, *dL_db2;
+} pings_mlp_job;
+PINGS_API int pings_mlp_forward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* stream);
+PINGS_API size_t pings_mlp_backward_grouped_scratch_bytes(const pings_mlp_job* jobs, int njobs);
+PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* scratch,
+                                         void* stream);
+
+/* ------------------------------------------------------- exposure correction of the rendered image
+ * gaussian_renderer/__init__.py:449-461 (affine form): out[c, p] = sum_k M[c, k] img[k, p] + b[c] for the
+ * [3, H W] planes — the reference's `img.permute(1,2,0).view(-1,3) @ M^T + b`, a GEMM with K = N = 3 there.
+ * Backward: g_img (may be NULL), g_M [3,3], g_b [3]; sums in fp64, fixed order (bitwise reproducible).
+ * scratch: pings_exposure_backward_scratch_bytes(). */
+PINGS_API int pings_exposure_forward(const float* img, const float* M, const float* b, int64_t HW, float* out,
+                                     void* stream);
+PINGS_API size_t pings_exposure_backward_scratch_bytes(void);
+PINGS_API int pings_exposure_backward(const float* img, const float* M, const float* g_out, int64_t HW,
+                                      void* scratch, float* g_img, float* g_M, float* g_b, void* stream);
+
 /* ------------------------------------------------------- spawn_gaussians
  * Replaces the tensor code of `spawn_gaussians` around the five decoder MLPs
  * (gaussian_splatting/gaussian_renderer/__init__.py:469-778).  Call order for one view:

@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(Dims d, const float* __res
 // operand chaining), which accumulates Y^T over the four blocks in ONE accumulator initialised with b2: no
 // cross-wave sum.  132 MFMAs per tile and wave; the next tile's x is in flight meanwhile.  Results are bitwise those
 // of the workgroup kernel's fma order up to the order of the hidden-block sum, i.e. within 1e-6.
-__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
-                                                              const float* __restrict__ W1, const float* __restrict__ b1,
-                                                              const float* __restrict__ W2, const float* __restrict__ b2,
-                                                              float* __restrict__ y) {
+__device__ __forceinline__ void mlp_fwd_wave_body(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                  const float* __restrict__ W1, const float* __restrict__ b1,
+                                                  const float* __restrict__ W2, const float* __restrict__ b2,
+                                                  float* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   // ---- weight fragments
@@ -260,6 +260,33 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_wave_kernel(long long N, int I
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                              const float* __restrict__ W1, const float* __restrict__ b1,
+                                                              const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              float* __restrict__ y) {
+  mlp_fwd_wave_body(N, IN, OUT, x, W1, b1, W2, b2, y);
+}
+
+// Several decoders over the same rows in ONE launch (blockIdx.y = decoder): the five spawn decoders of a view
+// (gaussian_renderer/__init__.py:605-716) share their row count and, four of them, their input; one grid of
+// 5 x 512 workgroups keeps every CU busy through the weight prologues and costs one launch instead of five.
+constexpr int MAX_JOBS = 8;
+struct MlpJobs {
+  const float *x[MAX_JOBS], *W1[MAX_JOBS], *b1[MAX_JOBS], *W2[MAX_JOBS], *b2[MAX_JOBS];
+  float* y[MAX_JOBS];
+  const float* gy[MAX_JOBS];
+  float* gx[MAX_JOBS];
+  float* partials[MAX_JOBS];
+  size_t per_block[MAX_JOBS];
+  float *gW1[MAX_JOBS], *gb1[MAX_JOBS], *gW2[MAX_JOBS], *gb2[MAX_JOBS];
+  int IN[MAX_JOBS], OUT[MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_grouped_kernel(long long N, MlpJobs j) {
+  const int g = blockIdx.y;
+  mlp_fwd_wave_body(N, j.IN[g], j.OUT[g], j.x[g], j.W1[g], j.b1[g], j.W2[g], j.b2[g], j.y[g]);
 }
 
 // ---------------------------------------------------------------- backward
@@ -472,11 +499,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
 // are added across the four waves in LDS (wave order) and written as one partial per workgroup, summed by
 // mlp_reduce_kernel in fixed order: bitwise reproducible.
 constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
-__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
-                                                              const float* __restrict__ gy, const float* __restrict__ W1,
-                                                              const float* __restrict__ b1, const float* __restrict__ W2,
-                                                              float* __restrict__ gx, float* __restrict__ partials,
-                                                              size_t per_block) {
+__device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                  const float* __restrict__ gy, const float* __restrict__ W1,
+                                                  const float* __restrict__ b1, const float* __restrict__ W2,
+                                                  float* __restrict__ gx, float* __restrict__ partials,
+                                                  size_t per_block) {
   __shared__ float sW1[128 * BW_LD];        // W1[hid][i], zero beyond IN
   __shared__ float sW2[32 * 129];           // W2[o][hid], zero beyond OUT
   __shared__ float sT[4][2][32 * BW_LD];    // per wave: H^T and gH^T as [hid_local][row]
@@ -643,6 +670,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
   for (int e = tid; e < nW2; e += 256) P[nW1 + e] = sW2[(e >> 7) * 129 + (e & 127)];
   if (tid < 128) P[nW1 + nW2 + tid] = sB[tid];
   if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sB[128 + tid];
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                              const float* __restrict__ gy, const float* __restrict__ W1,
+                                                              const float* __restrict__ b1, const float* __restrict__ W2,
+                                                              float* __restrict__ gx, float* __restrict__ partials,
+                                                              size_t per_block) {
+  mlp_bwd_wave_body(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block);
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_grouped_kernel(long long N, MlpJobs j) {
+  const int g = blockIdx.y;
+  mlp_bwd_wave_body(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
+                    j.per_block[g]);
 }
 
 // ---------------------------------------------------------------- backward of the SDF decoder shape: HID = 64, OUT = 1
@@ -852,6 +893,27 @@ __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblock
   else gb2[e - nW1 - nW2 - HID] = s;
 }
 
+__global__ void mlp_reduce_grouped_kernel(MlpJobs j, int nblocks, int HID) {
+  const int g = blockIdx.y;
+  const size_t per_block = j.per_block[g];
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_block) return;
+  const float* partials = j.partials[g];
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += partials[(size_t)(b + u) * per_block + e];
+  }
+  for (; b < nblocks; ++b) a[0] += partials[(size_t)b * per_block + e];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  const size_t nW1 = (size_t)HID * j.IN[g], nW2 = (size_t)j.OUT[g] * HID;
+  if (e < nW1) j.gW1[g][e] = s;
+  else if (e < nW1 + nW2) j.gW2[g][e - nW1] = s;
+  else if (e < nW1 + nW2 + HID) j.gb1[g][e - nW1 - nW2] = s;
+  else j.gb2[g][e - nW1 - nW2 - HID] = s;
+}
+
 int check_dims(int64_t N, int IN, int HID, int OUT) {
   PINGS_ARG_CHECK(N >= 0, "negative N");
   PINGS_ARG_CHECK(IN > 0 && IN <= MAX_INP, "IN must be in 1..64");
@@ -994,6 +1056,76 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
                      st, reinterpret_cast<const float*>(scratch), grid, per_block, IN, HID, OUT, dL_dW1,
                      dL_db1, dL_dW2, dL_db2);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+// ---------------------------------------------------------------- grouped launches (several decoders, same rows)
+namespace {
+int fill_jobs(const pings_mlp_job* jobs, int njobs, MlpJobs& J) {
+  PINGS_ARG_CHECK(jobs && njobs > 0 && njobs <= MAX_JOBS, "1..8 jobs");
+  for (int g = 0; g < njobs; ++g) {
+    const pings_mlp_job& q = jobs[g];
+    PINGS_ARG_CHECK(q.IN > 0 && q.IN <= 32 && q.OUT > 0 && q.OUT <= OUTP, "grouped MLP: IN <= 32, OUT <= 32");
+    PINGS_ARG_CHECK(q.x && q.W1 && q.b1 && q.W2 && q.b2, "null pointer in job");
+    J.x[g] = q.x; J.W1[g] = q.W1; J.b1[g] = q.b1; J.W2[g] = q.W2; J.b2[g] = q.b2; J.y[g] = q.y;
+    J.gy[g] = q.dL_dy; J.gx[g] = q.dL_dx; J.gW1[g] = q.dL_dW1; J.gb1[g] = q.dL_db1; J.gW2[g] = q.dL_dW2;
+    J.gb2[g] = q.dL_db2; J.IN[g] = q.IN; J.OUT[g] = q.OUT;
+    J.per_block[g] = partial_floats(q.IN, 128, q.OUT);
+    J.partials[g] = nullptr;
+  }
+  return PINGS_OK;
+}
+}  // namespace
+
+PINGS_API int pings_mlp_forward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* stream) {
+  MlpJobs J;
+  if (int e = fill_jobs(jobs, njobs, J)) return e;
+  PINGS_ARG_CHECK(N >= 0, "negative N");
+  if (N == 0) return PINGS_OK;
+  for (int g = 0; g < njobs; ++g) PINGS_ARG_CHECK(J.y[g] != nullptr, "null output");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope ps("mlp_fwd", st);
+  // two resident workgroups per CU over ALL jobs together: every workgroup stages its weights once and then walks
+  // njobs times more tiles than in a per-decoder launch of 512 workgroups
+  const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
+  const long long cap = 512 / njobs;   // floor: one workgroup too many would run alone in a second round
+  const unsigned grid_w = (unsigned)(want < cap ? want : cap);
+  hipLaunchKernelGGL(mlp_fwd_wave_grouped_kernel, dim3(grid_w, njobs), dim3(256), 0, st, (long long)N, J);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API size_t pings_mlp_backward_grouped_scratch_bytes(const pings_mlp_job* jobs, int njobs) {
+  size_t total = 0;
+  if (!jobs) return 0;
+  for (int g = 0; g < njobs; ++g) total += sizeof(float) * partial_floats(jobs[g].IN, 128, jobs[g].OUT) * 256;
+  return total;
+}
+
+PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* scratch,
+                                         void* stream) {
+  MlpJobs J;
+  if (int e = fill_jobs(jobs, njobs, J)) return e;
+  PINGS_ARG_CHECK(N > 0 && scratch, "grouped backward needs rows and scratch");
+  float* p = reinterpret_cast<float*>(scratch);
+  size_t max_pb = 0;
+  for (int g = 0; g < njobs; ++g) {
+    PINGS_ARG_CHECK(J.gy[g] && J.gW1[g] && J.gb1[g] && J.gW2[g] && J.gb2[g], "null gradient pointer in job");
+    J.partials[g] = p;
+    p += J.per_block[g] * 256;
+    if (J.per_block[g] > max_pb) max_pb = J.per_block[g];
+  }
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope ps("mlp_bwd", st);
+  // one resident workgroup per CU over all jobs together (see the forward)
+  const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
+  const long long cap = 256 / njobs;   // floor (see the forward)
+  const int grid_w = (int)(want < cap ? want : cap);
+  hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w, njobs), dim3(256), 0, st, (long long)N, J);
+  PINGS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mlp_reduce_grouped_kernel, dim3((unsigned)pings::ceil_div<size_t>(max_pb, 256), njobs), dim3(256),
+                     0, st, J, grid_w, 128);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

@@ -39,3 +39,19 @@ def mlp_batch(decoder, features: torch.Tensor) -> torch.Tensor:
         l0, lo = decoder.layers[0], decoder.lout
         return _mlp.fused_mlp(features, l0.weight, l0.bias, lo.weight, lo.bias)
     return decoder.mlp_batch(features)
+
+
+def mlp_batch_group(decoders, features):
+    """`[d.mlp_batch(x) for d, x in zip(decoders, features)]` with ONE kernel launch each way when every decoder has
+    the shape of the shipped spawn decoders (hidden 128, input <= 32; pings.py:156-160), else decoder by decoder."""
+    if not features[0].is_cuda:
+        from . import _lib
+
+        raise _lib.PingsHipError("decoder.mlp_batch runs on the HIP device only (got a CPU tensor); "
+                                 "there is no CPU fallback")
+    if all(_supported(d) for d in decoders):
+        from . import mlp as _mlp
+
+        params = [(d.layers[0].weight, d.layers[0].bias, d.lout.weight, d.lout.bias) for d in decoders]
+        return _mlp.fused_mlp_group(list(features), params)
+    return [mlp_batch(d, x) for d, x in zip(decoders, features)]

@@ -61,8 +61,66 @@ def depth2normal(depth, mask, camera, img_scale: int = 1, weight=None):
     """depth [1,H,W], mask [1,H,W] bool -> [3,H,W] (point_utils.py:83-149); `weight` [1,H,W] is multiplied in."""
     if not depth.is_cuda:
         raise _lib.PingsHipError("depth2normal runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
-    f32 = lambda v: float(torch.as_tensor(v, dtype=torch.float32))
-    cx = f32(camera.prcppoint[0] * camera.image_width / img_scale)     # point_utils.py:102-103
-    cy = f32(camera.prcppoint[1] * camera.image_height / img_scale)
-    fx, fy = f32(camera.fx / img_scale), f32(camera.fy / img_scale)      # :107-108
+    # point_utils.py:102-108 computes these with fp32 tensor arithmetic on the device; `float(device tensor)` would be
+    # a blocking read-back per value and frame.  The principal point is read back ONCE per camera tensor
+    # (`_lib.host_values` remembers it on the tensor object) and the same fp32 operations run on the host.
+    import numpy as np
+    p0, p1 = (np.float32(v) for v in _lib.host_values(camera.prcppoint))
+    cx = float(p0 * np.float32(camera.image_width) / np.float32(img_scale))
+    cy = float(p1 * np.float32(camera.image_height) / np.float32(img_scale))
+    fx, fy = float(np.float32(camera.fx / img_scale)), float(np.float32(camera.fy / img_scale))      # :107-108
     return _Depth2Normal.apply(depth, mask, weight, cx, cy, fx, fy)
+
+
+# ------------------------------------------------------------------ exposure correction (gaussian_renderer :449-461)
+class _ExposureAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, M, b):
+        L = _lib.lib()
+        _declare_exposure(L)
+        x = img.detach().to(torch.float32).contiguous()
+        Mc, bc = M.detach().to(torch.float32).contiguous(), b.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x)
+        HW = x.shape[1] * x.shape[2]
+        _lib.check(L.pings_exposure_forward(x.data_ptr(), Mc.data_ptr(), bc.data_ptr(), HW, out.data_ptr(),
+                                            _lib.stream_ptr(x.device)), "pings_exposure_forward")
+        ctx.save_for_backward(x, Mc)
+        ctx.need_img = img.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        x, Mc = ctx.saved_tensors
+        gg = g.detach().to(torch.float32).contiguous()
+        HW = x.shape[1] * x.shape[2]
+        dev = x.device
+        g_img = torch.empty_like(x) if ctx.need_img else None
+        gMb = torch.empty(12, dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.pings_exposure_backward_scratch_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(L.pings_exposure_backward(x.data_ptr(), Mc.data_ptr(), gg.data_ptr(), HW, scratch.data_ptr(),
+                                             g_img.data_ptr() if g_img is not None else None, gMb.data_ptr(),
+                                             gMb.data_ptr() + 36, _lib.stream_ptr(dev)), "pings_exposure_backward")
+        return g_img, gMb[:9].view(3, 3), gMb[9:]
+
+
+def _declare_exposure(L):
+    if getattr(L, "_exposure_declared", False):
+        return
+    import ctypes as C
+    vp = C.c_void_p
+    L.pings_exposure_forward.restype = C.c_int
+    L.pings_exposure_forward.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+    L.pings_exposure_backward_scratch_bytes.restype = C.c_size_t
+    L.pings_exposure_backward_scratch_bytes.argtypes = []
+    L.pings_exposure_backward.restype = C.c_int
+    L.pings_exposure_backward.argtypes = [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    L._exposure_declared = True
+
+
+def exposure_affine(img: torch.Tensor, exposure_mat: torch.Tensor, exposure_offset: torch.Tensor) -> torch.Tensor:
+    """`(img.permute(1,2,0).view(-1,3) @ M.T + b)` back in [3,H,W] (gaussian_renderer/__init__.py:454-458) as one
+    streaming kernel each way instead of three K = 3 GEMMs and a 2M-row bias reduction."""
+    if not img.is_cuda:
+        raise _lib.PingsHipError("exposure_affine runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+    return _ExposureAffine.apply(img, exposure_mat, exposure_offset)

@@ -13,6 +13,12 @@ import torch
 from . import _lib
 
 
+class _CJob(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("IN", C.c_int32), ("OUT", C.c_int32), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("W2", C.c_void_p), ("b2", C.c_void_p), ("y", C.c_void_p), ("dL_dy", C.c_void_p), ("dL_dx", C.c_void_p),
+                ("dL_dW1", C.c_void_p), ("dL_db1", C.c_void_p), ("dL_dW2", C.c_void_p), ("dL_db2", C.c_void_p)]
+
+
 def _declare(L):
     if getattr(L, "_mlp_declared", False):
         return
@@ -23,6 +29,12 @@ def _declare(L):
     L.pings_mlp_forward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pings_mlp_backward.restype = C.c_int
     L.pings_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pings_mlp_forward_grouped.restype = C.c_int
+    L.pings_mlp_forward_grouped.argtypes = [C.POINTER(_CJob), i32, i64, vp]
+    L.pings_mlp_backward_grouped_scratch_bytes.restype = C.c_size_t
+    L.pings_mlp_backward_grouped_scratch_bytes.argtypes = [C.POINTER(_CJob), i32]
+    L.pings_mlp_backward_grouped.restype = C.c_int
+    L.pings_mlp_backward_grouped.argtypes = [C.POINTER(_CJob), i32, i64, vp, vp]
     L._mlp_declared = True
 
 
@@ -75,3 +87,79 @@ def fused_mlp(x, W1, b1, W2, b2):
     if not supported(x.shape[1], W1.shape[0], W2.shape[0]):
         raise NotImplementedError(f"fused_mlp: unsupported dims IN={x.shape[1]} HID={W1.shape[0]} OUT={W2.shape[0]}")
     return _FusedMLP.apply(x, W1, b1, W2, b2)
+
+
+def group_supported(xs, params) -> bool:
+    """All jobs: hidden 128, IN <= 32, OUT <= 32, same row count (the shape of every shipped spawn decoder)."""
+    n = xs[0].shape[0]
+    return all(x.shape[0] == n and x.shape[1] <= 32 and W1.shape[0] == 128 and W2.shape[0] <= 32 and W2.shape[1] == 128
+               for x, (W1, b1, W2, b2) in zip(xs, params)) and len(xs) <= 8
+
+
+class _FusedMLPGroup(torch.autograd.Function):
+    """J decoders over the same rows: one `pings_mlp_forward_grouped` launch, one `pings_mlp_backward_grouped` (+ its
+    fixed-order reduce).  Inputs: x_0 .. x_{J-1}, then W1, b1, W2, b2 of every job; outputs y_0 .. y_{J-1}."""
+
+    @staticmethod
+    def forward(ctx, J, *args):
+        L = _lib.lib()
+        _declare(L)
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        xs = [f(t) for t in args[:J]]
+        ps = [f(t) for t in args[J:]]
+        N = xs[0].shape[0]
+        dev = xs[0].device
+        jobs = (_CJob * J)()
+        ys = []
+        for g in range(J):
+            W1, b1, W2, b2 = ps[4 * g:4 * g + 4]
+            y = torch.empty(N, W2.shape[0], dtype=torch.float32, device=dev)
+            ys.append(y)
+            jobs[g] = _CJob(xs[g].data_ptr(), xs[g].shape[1], W2.shape[0], W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
+                            b2.data_ptr(), y.data_ptr(), None, None, None, None, None, None)
+        _lib.check(L.pings_mlp_forward_grouped(jobs, J, N, _lib.stream_ptr(dev)), "pings_mlp_forward_grouped")
+        ctx.J = J
+        ctx.need_x = [t.requires_grad for t in args[:J]]
+        ctx.save_for_backward(*xs, *ps)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        L = _lib.lib()
+        J = ctx.J
+        saved = ctx.saved_tensors
+        xs, ps = saved[:J], saved[J:]
+        N = xs[0].shape[0]
+        dev = xs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        jobs = (_CJob * J)()
+        gxs, gps, keep = [], [], []
+        for g in range(J):
+            W1, b1, W2, b2 = ps[4 * g:4 * g + 4]
+            IN, OUT = xs[g].shape[1], W2.shape[0]
+            gy = gys[g]
+            gy = torch.zeros(N, OUT, **f32) if gy is None else gy.detach().to(torch.float32).contiguous()
+            keep.append(gy)
+            gx = torch.empty(N, IN, **f32) if ctx.need_x[g] else None
+            flat = torch.empty(128 * IN + 128 + OUT * 128 + OUT, **f32)
+            gW1, gb1 = flat[:128 * IN].view(128, IN), flat[128 * IN:128 * IN + 128]
+            gW2, gb2 = flat[128 * IN + 128:128 * IN + 128 + OUT * 128].view(OUT, 128), flat[128 * IN + 128 + OUT * 128:]
+            gxs.append(gx)
+            gps += [gW1, gb1, gW2, gb2]
+            jobs[g] = _CJob(xs[g].data_ptr(), IN, OUT, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), None,
+                            gy.data_ptr(), gx.data_ptr() if gx is not None else None, gW1.data_ptr(), gb1.data_ptr(),
+                            gW2.data_ptr(), gb2.data_ptr())
+        scratch = torch.empty(L.pings_mlp_backward_grouped_scratch_bytes(jobs, J), dtype=torch.uint8, device=dev)
+        _lib.check(L.pings_mlp_backward_grouped(jobs, J, N, scratch.data_ptr(), _lib.stream_ptr(dev)),
+                   "pings_mlp_backward_grouped")
+        return (None, *gxs, *gps)
+
+
+def fused_mlp_group(xs, params):
+    """[y_j = relu(x_j W1_j^T + b1_j) W2_j^T + b2_j]: `xs` list of [N, IN_j], `params` list of (W1, b1, W2, b2)."""
+    if not xs[0].is_cuda:
+        raise _lib.PingsHipError("fused_mlp_group runs on the HIP device only (no CPU fallback)")
+    if xs[0].shape[0] == 0 or not group_supported(xs, params):
+        return [fused_mlp(x, *p) for x, p in zip(xs, params)]
+    flat = [t for p in params for t in p]
+    return list(_FusedMLPGroup.apply(len(xs), *xs, *flat))

@@ -52,6 +52,7 @@ def spawn_gaussians(neural_points_data: Dict,
                     unit_scale_ratio: float = 0.2,
                     scale_filter_ratio: float = 0.2,
                     record_shifted: bool = False,
+                    _sel=None,
                     ):
     """Spawn K Gaussians per (visible, valid) neural point (gaussian_renderer/__init__.py:469-778).
 
@@ -78,7 +79,9 @@ def spawn_gaussians(neural_points_data: Dict,
         mask = visible_mask
     elif valid is not None:
         mask = valid
-    if mask is not None:
+    if _sel is not None:                        # `render` already counted the mask rows (one read-back for both counts)
+        sel, n = _sel
+    elif mask is not None:
         _lib.note_sync("spawn_mask_nonzero")    # reference: boolean-mask indexing at :563-569
         sel = torch.nonzero(mask).view(-1)      # features[cat(sel, -1)][:-1] == features[sel]  (:563-569,600)
         n = int(sel.shape[0])
@@ -99,11 +102,9 @@ def spawn_gaussians(neural_points_data: Dict,
     # xyz / rot / scale read the plain geo feature; alpha additionally the view distance when dist_concat_on (:672-675)
     geo_plain = geo_in[:, :geo_feat.shape[1]] if geo_in.shape[1] != geo_feat.shape[1] else geo_in
 
-    xyz_raw = _dec.mlp_batch(m_xyz, geo_plain)
-    rot_raw = _dec.mlp_batch(m_rot, geo_plain)
-    scale_raw = _dec.mlp_batch(m_scale, geo_plain)
-    alpha_raw = _dec.mlp_batch(m_alpha, geo_in)
-    color_raw = _dec.mlp_batch(m_color, col_in)
+    # the five decoders over the same rows: one launch forward, one backward (csrc/mlp.hip, grouped kernels)
+    xyz_raw, rot_raw, scale_raw, alpha_raw, color_raw = _dec.mlp_batch_group(
+        [m_xyz, m_rot, m_scale, m_alpha, m_color], [geo_plain, geo_plain, geo_plain, geo_in, col_in])
 
     dist_ratio = (view_dist / z_far) if (have_cam and dist_adaptive_scale) else None
     sp = _spawn.activate(xyz_raw, rot_raw, scale_raw, alpha_raw, color_raw, pos, quat,
@@ -137,6 +138,9 @@ def spawn_gaussians(neural_points_data: Dict,
 
 
 # ------------------------------------------------------------------ render
+_CONST_TENSORS: Dict = {}   # (device, host values) -> device tensor of constants (see _settings)
+
+
 def _settings(viewpoint_camera, gs_type, height, width, tanfovx, tanfovy, bg_color, scaling_modifier, down_rate,
               front_only_on, device):
     common = dict(image_height=height, image_width=width, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
@@ -147,11 +151,21 @@ def _settings(viewpoint_camera, gs_type, height, width, tanfovx, tanfovy, bg_col
     if gs_type == "gaussian_surfel":
         # both tensors are built from host numbers (:137-142, cameras.py:201-205); the numbers ride along so that the
         # rasteriser does not have to read them back from the device every frame
-        flags = [True, True, True, True, bool(front_only_on)]
-        cfg = _lib.with_host_values(torch.tensor(flags, dtype=torch.float32, device=device), flags)
-        pb = viewpoint_camera.full_patch(down_rate)         # == [0, 0, height - 1, width - 1] by its definition
-        if getattr(pb, "_pings_host", None) is None:
-            _lib.with_host_values(pb, [0, 0, height - 1, width - 1])
+        # A `torch.tensor(host list, device=...)` is a BLOCKING host-to-device copy: it waits for every kernel already
+        # queued (measured: 0.5 ms each, three per frame, with the previous iteration's backward still running).  The
+        # two tensors hold constants, so they are built once per (device, value) and reused.
+        flags = (True, True, True, True, bool(front_only_on))
+        key = (str(device), flags)
+        cfg = _CONST_TENSORS.get(key)
+        if cfg is None:
+            cfg = _CONST_TENSORS[key] = _lib.with_host_values(
+                torch.tensor(flags, dtype=torch.float32, device=device), flags)
+        patch = (0, 0, height - 1, width - 1)               # == camera.full_patch(down_rate) by its definition
+        key = (str(device), patch)
+        pb = _CONST_TENSORS.get(key)
+        if pb is None:
+            pb = _CONST_TENSORS[key] = _lib.with_host_values(
+                torch.tensor(patch, dtype=torch.float32, device=device), patch)
         return _rast.SurfelGaussianRasterizer(_rast.SurfelRasterizationSettings(
             patch_bbox=pb, prcppoint=viewpoint_camera.prcppoint, config=cfg, **common))
     return _rast.GS3DGaussianRasterizer(_rast.GS3DRasterizationSettings(**common))
@@ -215,8 +229,12 @@ def render(viewpoint_camera,
         return None                     # :264-265
     visible = rasterizer.markVisible(neural_points_data["position"])
     n_all = visible.shape[0]
-    _lib.note_sync("render_visible_count")                  # reference: :219
-    n_vis = int(torch.sum(visible).item())
+    # ONE read-back for both counts the control flow needs: visible points (reference: `.item()` at :219) and rows
+    # of the spawn mask (reference: boolean-mask indexing at :563-569, a second synchronisation there)
+    valid = neural_points_data.get("valid_mask", None)
+    mask = visible & valid if valid is not None else visible
+    _lib.note_sync("render_visible_counts")
+    n_vis, n_sel = (int(v) for v in torch.stack((visible.sum(), mask.sum())).tolist())
     if n_vis == 0:
         if verbose:
             print("[Render] No visible neural points, skip this frame {}".format(viewpoint_camera.uid))
@@ -227,11 +245,13 @@ def render(viewpoint_camera,
             print("[Render] Too small ratio of visible neural points, skip this frame {}".format(viewpoint_camera.uid))
         return None
 
+    sel = torch.nonzero_static(mask, size=n_sel).view(-1) if n_sel >= 10 else None   # size known: no second sync
     spawned = spawn_gaussians(neural_points_data, decoders, visible, viewpoint_camera.camera_center,
                               dist_concat_on, view_concat_on, z_far=z_far,
                               learn_color_residual=learn_color_residual, gs_type=gs_type,
                               displacement_range_ratio=displacement_range_ratio,
-                              max_scale_ratio=max_scale_ratio, unit_scale_ratio=unit_scale_ratio)
+                              max_scale_ratio=max_scale_ratio, unit_scale_ratio=unit_scale_ratio,
+                              _sel=(sel, n_sel))
     if spawned is None:
         e = lambda c: torch.empty((0, c), dtype=dtype, device=device)
         means3D, scales, rotations, opacity, colors = e(3), e(3), e(4), e(1), e(3)
@@ -257,12 +277,15 @@ def render(viewpoint_camera,
         screenspace_points.retain_grad()
     except Exception:
         pass
-    _lib.note_sync("render_nan_assert")                     # reference: :305-306
-    assert not bool(torch.isnan(rotations).any()), "NaN in rotation"
+    # reference: `assert not torch.isnan(rotations).any()` (:305-306) right here, a synchronisation of its own.  The
+    # flag is computed here and READ after the rasteriser call, whose instance-count read-back has drained the stream
+    # anyway (a NaN quaternion is culled by the kernels: non-finite radius), so the assert costs no extra wait.
+    nan_flag = torch.isnan(rotations).any()
 
     out = rasterizer(means3D=means3D, means2D=screenspace_points, colors_precomp=colors, opacities=opacity,
                      scales=scales, rotations=rotations, theta=viewpoint_camera.cam_rot_delta,
                      rho=viewpoint_camera.cam_trans_delta)
+    assert not bool(nan_flag), "NaN in rotation"
     if gs_type == "gaussian_surfel":
         rendered_image, rendered_normal, rendered_depth, rendered_alpha, radii, contributions = out
         alpha_detached = rendered_alpha.detach()
@@ -288,10 +311,10 @@ def render(viewpoint_camera,
 
     if correct_exposure:                # :449-461
         if correct_exposure_affine:
-            c, h, w = rendered_image.shape
-            flat = rendered_image.permute(1, 2, 0).reshape(-1, 3)
-            flat = flat @ viewpoint_camera.exposure_mat.T + viewpoint_camera.exposure_offset
-            rendered_image = flat.view(h, w, 3).permute(2, 0, 1)
+            # reference: img.permute(1,2,0).view(-1,3) @ exposure_mat.T + exposure_offset (:454-458), i.e. three
+            # K = 3 GEMMs and a 2M-row reduction per step (1.27 ms at 1080p); here one streaming kernel each way
+            rendered_image = _img.exposure_affine(rendered_image, viewpoint_camera.exposure_mat,
+                                                  viewpoint_camera.exposure_offset)
         else:
             rendered_image = torch.exp(viewpoint_camera.exposure_a) * rendered_image + viewpoint_camera.exposure_b
     results.update({"render": rendered_image})

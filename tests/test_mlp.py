@@ -59,3 +59,42 @@ def test_fused_mlp_is_deterministic_and_handles_empty():
     assert e.shape == (0, 24)
     ge = torch.autograd.grad(e.sum(), [W1, b1], allow_unused=True)
     assert all(t is None or (t == 0).all() for t in ge)
+
+
+@pytest.mark.gpu
+def test_grouped_decoders_equal_the_single_launches_bit_for_bit():
+    """The five spawn decoders in ONE launch each way (pings_mlp_forward_grouped / _backward_grouped) against five
+    single launches: outputs and every gradient identical bits (same kernel body, blockIdx.y = decoder); three of the
+    decoders share one input tensor, whose gradient autograd sums."""
+    from pings_amd.mlp import fused_mlp, fused_mlp_group
+
+    g = torch.Generator().manual_seed(4)
+    N = 5000 + 17
+    geo = torch.randn(N, 32, generator=g).cuda()
+    col = torch.randn(N, 19, generator=g).cuda()
+    shapes = [(32, 24), (32, 32), (32, 24), (32, 8), (19, 24)]
+
+    def make():
+        gg = torch.Generator().manual_seed(5)
+        ps = []
+        for fin, fout in shapes:
+            ps.append(tuple(torch.randn(*sh, generator=gg).cuda().requires_grad_(True)
+                            for sh in ((128, fin), (128,), (fout, 128), (fout,))))
+        return geo.clone().requires_grad_(True), col.clone().requires_grad_(True), ps
+
+    ups = [torch.randn(N, fo, generator=g).cuda() for _, fo in shapes]
+    res = []
+    for grouped in (True, False):
+        xg, xc, ps = make()
+        xs = [xg, xg, xg, xg, xc]
+        ys = fused_mlp_group(xs, ps) if grouped else [fused_mlp(x, *p) for x, p in zip(xs, ps)]
+        loss = sum((y * u).sum() for y, u in zip(ys, ups))
+        grads = torch.autograd.grad(loss, [xg, xc] + [t for p in ps for t in p])
+        res.append((ys, grads))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for i, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        if i == 0:      # the shared input: sum of four gradients, added by autograd in (possibly) another order
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(a, b), i

@@ -111,3 +111,31 @@ def test_render_none_cases():
     assert render(cam, None, data, decs, None, bg, view_concat_on=True, min_visible_neural_point_ratio=0.999,
                   replay_mode=True) is None
     assert render(cam, None, data, decs, None, bg, view_concat_on=True) is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(96, 160), (37, 53)])
+def test_exposure_affine_matches_the_reference_expression(hw):
+    """`pings_exposure_forward/backward` vs the reference's own expression (gaussian_renderer/__init__.py:454-458) in
+    fp64: image, and gradients w.r.t. the image, the 3x3 matrix and the offset; bitwise reproducible."""
+    from pings_amd.image_ops import exposure_affine
+
+    H, W = hw
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(3, H, W, generator=g)
+    M = torch.eye(3) * 0.9 + 0.1 * torch.randn(3, 3, generator=g)
+    b = 0.05 * torch.randn(3, generator=g)
+    up = torch.randn(3, H, W, generator=g)
+    i64, M64, b64 = (t.double().requires_grad_(True) for t in (img, M, b))
+    ref = (i64.permute(1, 2, 0).reshape(-1, 3) @ M64.T + b64).view(H, W, 3).permute(2, 0, 1)
+    gref = torch.autograd.grad((ref * up.double()).sum(), [i64, M64, b64])
+    outs = []
+    for _ in range(2):
+        ih, Mh, bh = (t.cuda().requires_grad_(True) for t in (img, M, b))
+        out = exposure_affine(ih, Mh, bh)
+        outs.append((out,) + torch.autograd.grad((out * up.cuda()).sum(), [ih, Mh, bh]))
+    assert rel_err(outs[0][0], ref) <= 1e-6
+    for a, r in zip(outs[0][1:], gref):
+        assert rel_err(a, r) <= 1e-5
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
