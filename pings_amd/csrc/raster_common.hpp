@@ -100,6 +100,10 @@ struct BinState {
   uint32_t* tile_order;  // [2][num_tiles] tiles by descending work: [0] by list length (forward), [1] by the largest
                          // per-pixel contributor count (backward) — longest-processing-time-first dispatch order
   uint32_t* tile_work;   // [num_tiles] scratch of the two orderings
+  // segmented blend of long tile lists (raster_fwd.hip, "forward of LONG tile lists")
+  uint32_t seg_max_units;      // capacity: every list of more than 2 * SEG entries cut into SEG-entry units
+  uint32_t *seg_head, *seg_unit_tile, *seg_unit_seg, *seg_tile_unit0;
+  float *seg_P, *seg_slab;
   char* temp;
   size_t temp_bytes;
   size_t total;
@@ -111,6 +115,7 @@ struct ImageState {
   size_t total;
 };
 
+uint32_t blend_segment_entries();
 GeomState carve_geom(void* blob, int P, int num_tiles);
 // tile_order[i] = i-th tile in descending `work` (ties in any order: scheduling only, results do not depend on it)
 int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st);

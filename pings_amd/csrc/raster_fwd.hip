@@ -64,6 +64,12 @@ int occlusion_buckets(int num_tiles) {
   return nb;
 }
 
+// entries per segment of the segmented blend of long tile lists (0 = off); PINGS_BLEND_SEG overrides (tests, A/B)
+uint32_t blend_segment_entries() {
+  if (const char* e = getenv("PINGS_BLEND_SEG")) return (uint32_t)atoi(e);
+  return 512u;
+}
+
 GeomState carve_geom(void* blob, int P, int num_tiles) {
   Carver c(blob);
   GeomState g;
@@ -112,6 +118,18 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.slot_val = c.take<uint32_t>(n);
   b.tile_order = c.take<uint32_t>(2 * (size_t)num_tiles);
   b.tile_work = c.take<uint32_t>((size_t)num_tiles);
+  // units of SEG entries for lists beyond 2 SEG: at most I / SEG + I / (2 SEG) of them
+  {
+    const size_t sg = (size_t)blend_segment_entries();
+    b.seg_max_units = sg ? (uint32_t)(n / sg + n / (2 * sg) + 64) : 1u;
+    if (b.seg_max_units > (1u << 20)) b.seg_max_units = 1u << 20;   // forced tiny segments (tests): capacity is checked on device
+  }
+  b.seg_head = c.take<uint32_t>(4);
+  b.seg_unit_tile = c.take<uint32_t>(b.seg_max_units);
+  b.seg_unit_seg = c.take<uint32_t>(b.seg_max_units);
+  b.seg_tile_unit0 = c.take<uint32_t>((size_t)num_tiles);
+  b.seg_P = c.take<float>((size_t)b.seg_max_units * 256);
+  b.seg_slab = c.take<float>((size_t)b.seg_max_units * 256 * 10);
   b.temp_bytes = sort_temp_bytes((int64_t)n);
   b.temp = c.take<char>(b.temp_bytes);
   b.total = c.off;
@@ -1080,7 +1098,8 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
-    uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order) {
+    uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order,
+    const uint32_t* __restrict__ seg_tile_unit0) {
   __shared__ float4 sA[64], sB[64], sC[64], sD[64];
   __shared__ uint32_t sSlot[64];
   __shared__ int sE[64];
@@ -1089,6 +1108,7 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
 
   const int lane = threadIdx.x;
   const int tile = (int)tile_order[blockIdx.x >> 2], q = blockIdx.x & 3;
+  if (seg_tile_unit0 && seg_tile_unit0[tile] != 0xFFFFFFFFu) return;   // a long list: blended in parallel segments
   const int tx = tile % p.gx, ty = tile / p.gx;
   const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
   const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
@@ -1223,6 +1243,283 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
     } else {
       out_depth[pix_id] = D;
     }
+  }
+}
+
+// ---------------------------------------------------------------- forward of LONG tile lists, in parallel segments
+// A wave blends ~8 list entries per microsecond, one after the other: a tile whose list holds 14,000 records (the
+// horizon of a street scene: thousands of edge-on surfels behind one another, none of them opaque) keeps ONE wave per
+// quadrant busy for 1.7 ms while the rest of the chip has long finished.  Front-to-back compositing is associative:
+//     (C, T) of a list = (C_a + T_a C_b, T_a T_b)  for the list split into a | b,
+// so lists longer than SEG_THR entries are cut into segments of SEG entries, each blended by its own wave:
+//   pass T  every (tile, segment, quadrant) wave walks its segment and multiplies up (1 - alpha) per pixel — alpha
+//           evaluation only, the cheap half of the blend, and no termination test (that needs the transmittance in
+//           front, which is what this pass is producing);
+//   pass B  the wave multiplies the products of the segments in front of it — which is the transmittance its pixels
+//           start with, and also tells it whether a pixel has stopped before (the running value is monotone, so it
+//           stopped in segment s iff T_in(s) P(s) < T_EPS) — and then blends its segment EXACTLY like the serial
+//           kernel does: same alpha arithmetic, same stop rule, same per-instance weight sums, `n_contrib` in global
+//           list positions; colour / normal / depth partial sums, T and the last contributor go to a per-segment slab;
+//   pass C  one wave per (tile, quadrant) adds the slabs in list order and writes the pixel outputs.
+// What differs from the serial kernel is floating-point association only: T_in is a product of per-segment products
+// instead of one running product, the colour sum a sum of per-segment sums (relative 1e-6); the stop decision can
+// flip for a pixel whose transmittance sits within that rounding of 1e-4.  Lists up to SEG_THR entries never come
+// here, so every list-parity test against the oracle is untouched; `PINGS_BLEND_SEG=<entries>` forces a small
+// segment size (tests), 0 turns the path off.
+constexpr int SEG_SLAB = 10;           // floats per pixel in a segment slab: C0 C1 C2 N0 N1 N2 D T last(bits) touched
+
+// One workgroup: tiles with more than `thr` entries get ceil(L / seg) units; units of a tile are contiguous.
+// head[0] = number of units, head[1] = number of long tiles.  unit_tile[u], unit_seg[u]; tile_unit0[tile] (or ~0u).
+__global__ __launch_bounds__(1024) void seg_plan_kernel(const uint2* __restrict__ ranges, int num_tiles, uint32_t thr,
+                                                        uint32_t seg, uint32_t max_units, uint32_t* __restrict__ head,
+                                                        uint32_t* __restrict__ unit_tile, uint32_t* __restrict__ unit_seg,
+                                                        uint32_t* __restrict__ tile_unit0) {
+  __shared__ uint32_t sScan[1024];
+  __shared__ uint32_t sBase;
+  const int tid = threadIdx.x;
+  if (tid == 0) sBase = 0u;
+  __syncthreads();
+  for (int t0 = 0; t0 < num_tiles; t0 += 1024) {
+    const int t = t0 + tid;
+    uint32_t n = 0;
+    if (t < num_tiles) {
+      const uint32_t L = ranges[t].y - ranges[t].x;
+      if (L > thr) n = (L + seg - 1) / seg;
+    }
+    sScan[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t add = tid >= off ? sScan[tid - off] : 0u;
+      __syncthreads();
+      sScan[tid] += add;
+      __syncthreads();
+    }
+    const uint32_t base = sBase + sScan[tid] - n;
+    if (t < num_tiles) {
+      const bool fits = n > 0 && base + n <= max_units;   // a tile that does not fit stays with the serial kernel
+      tile_unit0[t] = fits ? base : 0xFFFFFFFFu;
+      if (fits) {
+        for (uint32_t k = 0; k < n; ++k) { unit_tile[base + k] = (uint32_t)t; unit_seg[base + k] = k; }
+      } else {
+        for (uint32_t k = 0; k < n && base + k < max_units; ++k) { unit_tile[base + k] = 0xFFFFFFFFu; unit_seg[base + k] = 1u; }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) sBase += sScan[1023];
+    __syncthreads();
+  }
+  if (tid == 0) head[0] = sBase < max_units ? sBase : max_units;
+}
+
+// PASS: 0 = transmittance products, 1 = blend
+template <int MODE, int PASS>
+__global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, uint32_t seg, const uint32_t* __restrict__ head,
+    const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, float* __restrict__ segP,
+    float* __restrict__ slab, float* __restrict__ inst_wq, uint32_t* __restrict__ inst_cntq) {
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
+  __shared__ uint32_t sSlot[64];
+  __shared__ int sE[64];
+  __shared__ float sW[64];
+  __shared__ uint32_t sCnt[64];
+
+  const int lane = threadIdx.x;
+  const uint32_t unit = blockIdx.x >> 2;
+  const int q = blockIdx.x & 3;
+  if (unit >= head[0] || unit_tile[unit] == 0xFFFFFFFFu) return;
+  const int tile = (int)unit_tile[unit];
+  const uint32_t sg = unit_seg[unit];
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
+  const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
+  const float pixf_x = (float)pix_x, pixf_y = (float)pix_y;
+  const float qx0 = (float)(tx * TILE + 8 * (q & 1)), qy0 = (float)(ty * TILE + 8 * (q >> 1));
+  float rx = 0.f, ry = 0.f;
+  if (MODE == MODE_SURFEL && PASS == 1) {
+    const float cxp = (p.prcp ? p.prcp[0] : 0.5f) * (float)p.W - 0.5f;
+    const float cyp = (p.prcp ? p.prcp[1] : 0.5f) * (float)p.H - 0.5f;
+    rx = (pixf_x - cxp) / p.fx;
+    ry = (pixf_y - cyp) / p.fy;
+  }
+  const uint2 range = ranges[tile];
+  const int L = (int)(range.y - range.x);
+  const int e_lo = (int)(sg * seg), e_hi = min(L, (int)((sg + 1) * seg));
+  const bool inside = pix_x < p.W && pix_y < p.H;
+  const size_t my = ((size_t)unit * 4 + q) * 64 + lane;
+
+  float T = 1.0f;
+  bool done = !inside;
+  if (PASS == 1) {
+    // transmittance in front of this segment; stopped before it?
+    const size_t first = ((size_t)(unit - sg) * 4 + q) * 64 + lane;
+    for (uint32_t s2 = 0; s2 < sg; ++s2) {
+      T *= segP[first + (size_t)s2 * 256];
+      if (T < T_EPS) { done = true; break; }
+    }
+  }
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
+  uint32_t last = 0;
+
+  uint32_t f_slot = 0, f_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
+  bool f_ok = false;
+  auto fetch = [&](int base) {
+    const int e = base + lane;
+    f_ok = e < e_hi;
+    if (f_ok) {
+      f_slot = point_list[range.x + e];
+      f_g = gval[f_slot];
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+    }
+  };
+  if (e_lo < e_hi && !__all(done)) fetch(e_lo);
+
+  for (int base = e_lo; base < e_hi; base += 64) {
+    if (__all(done)) break;
+    const uint32_t slot = f_slot, g = f_g;
+    const float4 ra = f_a, rb = f_b;
+    const bool ok = f_ok;
+    if (base + 64 < e_hi) fetch(base + 64);
+    bool rel = false;
+    if (ok) {
+      const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
+      rel = !footprint_misses_rect(ra.x, ra.y, rb.x, rb.y, rb.z, thr, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+    }
+    const unsigned long long bal = __ballot(rel);
+    const int n = __popcll(bal);
+    if (rel) {
+      const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      sA[at] = ra;
+      sB[at] = rb;
+      if (PASS == 1) {
+        sC[at] = rec[4 * (size_t)g + 2];
+        if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+        sSlot[at] = slot;
+        sE[at] = base + lane;
+      }
+    }
+    if (PASS == 1) {
+      sW[lane] = 0.f;
+      if (MODE == MODE_3DGS) sCnt[lane] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for (int j = 0; j < n; ++j) {
+      const float4 a = sA[j], b = sB[j];
+      const float dx = a.x - pixf_x;
+      const float p0 = -0.5f * (b.x * dx * dx);
+      const float pxy = b.y * dx;
+      const float dy = a.y - pixf_y;
+      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+      if (PASS == 0) {
+        const bool valid = inside && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+        T = valid ? T * (1.0f - alpha) : T;
+        continue;
+      }
+      const float4 c = sC[j];
+      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == MODE_SURFEL) nn = sD[j];
+      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      const float test_T = T * (1.0f - alpha);
+      const bool stop = valid && (test_T < T_EPS);
+      const bool contrib = valid && !stop;
+      done = done || stop;
+      if (__any(contrib)) {
+        const float w = contrib ? alpha * T : 0.f;
+        C0 = fmaf(c.x, w, C0);
+        C1 = fmaf(c.y, w, C1);
+        C2 = fmaf(c.z, w, C2);
+        uint32_t touched = 0;
+        if (MODE == MODE_SURFEL) {
+          const float den = (nn.x * rx + nn.y * ry) + nn.z;
+          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+          N0 = fmaf(nn.x, w, N0);
+          N1 = fmaf(nn.y, w, N1);
+          N2 = fmaf(nn.z, w, N2);
+          D = fmaf(d, w, D);
+        } else {
+          D = fmaf(a.w, w, D);
+          touched = (contrib && test_T > 0.5f) ? 1u : 0u;
+        }
+        T = contrib ? test_T : T;
+        last = contrib ? (uint32_t)(sE[j] + 1) : last;
+        const float s = wave_reduce_sum_dpp(w);
+        if (lane == 63) sW[j] = s;
+        if (MODE == MODE_3DGS) {
+          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
+          if (lane == 63) sCnt[j] = cn;
+        }
+      }
+      if (__all(done)) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (PASS == 1 && lane < n) {
+      const float w = sW[lane];
+      if (w != 0.f) {
+        inst_wq[4 * (size_t)sSlot[lane] + q] = w;
+        if (MODE == MODE_3DGS) inst_cntq[4 * (size_t)sSlot[lane] + q] = sCnt[lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (PASS == 0) {
+    segP[my] = T;
+  } else {
+    float* o = slab + ((size_t)unit * 4 + q) * 64 * SEG_SLAB + lane;
+    o[0] = C0; o[64] = C1; o[128] = C2; o[192] = N0; o[256] = N1; o[320] = N2; o[384] = D;
+    o[448] = T;                                     // transmittance behind this segment (its pixels' running value)
+    o[512] = __uint_as_float(last);
+    o[576] = done ? 1.f : 0.f;
+  }
+}
+
+// PASS C: first-segment waves add their tile's slabs in list order and write the pixel outputs.
+template <int MODE>
+__global__ __launch_bounds__(64) void blend_fwd_seg_combine_kernel(
+    KParams p, const uint2* __restrict__ ranges, uint32_t seg, const uint32_t* __restrict__ head,
+    const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, const float* __restrict__ slab,
+    float* __restrict__ out_color, float* __restrict__ out_normal, float* __restrict__ out_depth,
+    float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+  const int lane = threadIdx.x;
+  const uint32_t unit = blockIdx.x >> 2;
+  const int q = blockIdx.x & 3;
+  if (unit >= head[0] || unit_seg[unit] != 0u || unit_tile[unit] == 0xFFFFFFFFu) return;
+  const int tile = (int)unit_tile[unit];
+  const int tx = tile % p.gx, ty = tile / p.gx;
+  const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
+  const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
+  if (pix_x >= p.W || pix_y >= p.H) return;
+  const uint32_t L = ranges[tile].y - ranges[tile].x;
+  const uint32_t nseg = (L + seg - 1) / seg;
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f, T = 1.0f;
+  uint32_t last = 0;
+  for (uint32_t s2 = 0; s2 < nseg; ++s2) {
+    const float* o = slab + ((size_t)(unit + s2) * 4 + q) * 64 * SEG_SLAB + lane;
+    C0 += o[0]; C1 += o[64]; C2 += o[128]; N0 += o[192]; N1 += o[256]; N2 += o[320]; D += o[384];
+    const uint32_t l2 = __float_as_uint(o[512]);
+    if (l2 != 0u) { last = l2; T = o[448]; }          // the last segment that blended something holds T and n_contrib
+    if (o[576] != 0.f) break;                        // the pixel stopped inside (or before) this segment
+  }
+  const size_t HW = (size_t)p.W * p.H;
+  const size_t pix_id = (size_t)pix_y * p.W + pix_x;
+  const float A = 1.0f - T;
+  final_T[pix_id] = T;
+  n_contrib[pix_id] = last;
+  out_color[pix_id] = C0 + T * p.bg[0];
+  out_color[HW + pix_id] = C1 + T * p.bg[1];
+  out_color[2 * HW + pix_id] = C2 + T * p.bg[2];
+  out_alpha[pix_id] = A;
+  if (MODE == MODE_SURFEL) {
+    out_normal[pix_id] = N0;
+    out_normal[HW + pix_id] = N1;
+    out_normal[2 * HW + pix_id] = N2;
+    out_depth[pix_id] = D / fmaxf(A, DEPTH_ALPHA_EPS);
+  } else {
+    out_depth[pix_id] = D;
   }
 }
 
@@ -1768,13 +2065,35 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   hipLaunchKernelGGL((blend_fwd_kernel<M, L>), dim3(num_tiles), dim3(BLOCK / L), 0, st, kp, bs.ranges,  \
                      bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,      \
                      im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt, bs.inst_qmask, want_qmask)
+  // long lists in parallel segments (see blend_fwd_seg_kernel): PINGS_BLEND_SEG = entries per segment, 0 = off
+  const uint32_t seg = blend_segment_entries();
+  const bool seg_on = seg > 0 && I > (int64_t)num_tiles * (seg / 4) && I > 2 * (int64_t)seg;
 #define PINGS_BLEND_FWD_WAVE(M)                                                                        \
   do {                                                                                                 \
     if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_wq, 0, 16 * (size_t)I, st));                     \
     if (I > 0 && M == MODE_3DGS) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cntq, 0, 16 * (size_t)I, st)); \
+    if (seg_on) {                                                                                      \
+      hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, st, bs.ranges, num_tiles, 2u * seg, seg, \
+                         bs.seg_max_units, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_tile_unit0); \
+      PINGS_LAUNCH_CHECK();                                                                            \
+    }                                                                                                  \
     hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(4 * num_tiles), dim3(64), 0, st, kp, bs.ranges, \
                        bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
-                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order);             \
+                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order,              \
+                       seg_on ? bs.seg_tile_unit0 : nullptr);                                          \
+    if (seg_on) {                                                                                      \
+      const dim3 gseg(4u * bs.seg_max_units);                                                          \
+      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 0>), gseg, dim3(64), 0, st, kp, bs.ranges, bs.point_list, gs.rec, \
+                         bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
+                         bs.inst_wq, bs.inst_cntq);                                                    \
+      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 1>), gseg, dim3(64), 0, st, kp, bs.ranges, bs.point_list, gs.rec, \
+                         bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
+                         bs.inst_wq, bs.inst_cntq);                                                    \
+      hipLaunchKernelGGL((blend_fwd_seg_combine_kernel<M>), gseg, dim3(64), 0, st, kp, bs.ranges, seg, bs.seg_head, \
+                         bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_slab, out_color, out_normal, out_depth, \
+                         out_alpha, im.final_T, im.n_contrib);                                         \
+      PINGS_LAUNCH_CHECK();                                                                            \
+    }                                                                                                  \
     if (I > 0)                                                                                         \
       hipLaunchKernelGGL((combine_quadrants_kernel<M>), dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), \
                          dim3(256), 0, st, I, reinterpret_cast<const float4*>(bs.inst_wq),              \
