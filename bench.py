@@ -73,7 +73,8 @@ def pmc_traffic(stage, workload=None):
     summary records the SAME workload (gaussians / width / height / mode) as this run, otherwise None."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
-        files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("pmc_traffic.json"))
+        files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs
+                       if f.endswith("pmc_traffic.json") and not f.startswith("sdf_"))
         if not files:
             return None, None, None
         data = json.load(open(files[-1]))
@@ -85,7 +86,10 @@ def pmc_traffic(stage, workload=None):
             return None, None, None   # round-1 summaries carry no workload record; they were taken on the default
         for name, v in data.items():
             if name.startswith(stage + "_"):
-                return int(v["hbm_bytes_corrected"]), os.path.relpath(files[-1], os.path.dirname(root)), v.get("valu_insts")
+                # the calibrated figure where the summary has one (profiles/pmc_summary.py: this kernel's reads are
+                # not wide streaming reads, so the blanket x2 of the guide over-corrects them; profiles/pmc_calib.hip)
+                return (int(v.get("hbm_bytes_calibrated", v["hbm_bytes_corrected"])),
+                        os.path.relpath(files[-1], os.path.dirname(root)), v.get("valu_insts"))
     except Exception:
         pass
     return None, None, None
@@ -162,18 +166,25 @@ def cpu_baseline_raster(dev, P_sample=16000, W=480, H=272):
     torch.autograd.backward([img, nrm, dep, alp], [u.to(dev) for u in ups])
 
     def rel(a, b):
-        a, b = a.detach().double().cpu(), b.detach().double().cpu()
-        return float((a - b).abs().max() / max(b.abs().max().item(), 1e-30))
+        """[max-abs error / max|ref|, relative L2 error, entries off by more than 1e-4 max|ref|]"""
+        a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+        scale = max(b.abs().max().item(), 1e-30)
+        d = (a - b).abs()
+        return [float(f"{d.max().item() / scale:.3e}"), float(f"{(d.norm() / max(b.norm().item(), 1e-30)).item():.3e}"),
+                int((d > 1e-4 * scale).sum())]
 
-    parity = {"radii_equal": bool((radii.cpu() == out["radii"]).all())}
+    parity = {"format": "[max_rel_err, rel_l2_err, entries > 1e-4]", "radii_equal": bool((radii.cpu() == out["radii"]).all())}
     for k, t in zip(keys, (img, nrm, dep, alp)):
-        parity[k] = float(f"{rel(t, out[k]):.3e}")
-    parity["contributions"] = float(f"{rel(contrib, out['contributions']):.3e}")
+        parity[k] = rel(t, out[k])
+    parity["contributions"] = rel(contrib, out["contributions"])
     for name, a, b in zip(("d_means3D", "d_colors", "d_opacities", "d_scales", "d_rotations", "d_theta", "d_rho"),
                           [t.grad for t in hl] + [th.grad, rh.grad], grads):
-        parity[name] = float(f"{rel(a.reshape(b.shape), b):.3e}")
-    parity["note"] = ("HIP fp32 vs oracle fp32 on identical inputs; the oracle's own fp32-vs-fp64 distance on such "
-                      "scenes is 1e-5..2e-3 per gradient tensor (tests/test_raster.py prints both)")
+        parity[name] = rel(a.reshape(b.shape), b)
+    parity["note"] = ("HIP fp32 vs oracle fp32 on identical inputs.  Entries beyond 1e-4 are pixels (and the Gaussians "
+                      "under them) within fp32 rounding of a discrete decision of the blend - the alpha < 1/255 skip, "
+                      "the T < 1e-4 stop, the surfel-depth clamp - which two fp32 evaluations take differently; the "
+                      "oracle's own fp32-vs-fp64 distance on such scenes has the same few outliers "
+                      "(tests/test_raster.py::test_mid_size_scene_* prints and gates all three)")
     return {"value": round(W * H / dt / 1e6, 6), "unit": "Mpix/s", "cores": threads,
             "kind": "port",
             "sample": f"oracle/raster_cpu.py fp32 fwd+bwd, {P_sample} Gaussians of the same distribution at "
@@ -495,6 +506,15 @@ def bench_sdf_sweep(dev, steps, warmup, sizes=(200_000, 1_000_000, 5_000_000), w
                                          "achieved": round(alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg,
                                          "traffic": sdf_pmc_traffic(n_points, B)}}
+            tr = leg[f"B{B}"]["roofline"]["traffic"]
+            if tr:
+                # the kernel's reads are one 64-B half-line request per probe / row (profiles/pmc_calib.hip: FETCH_SIZE
+                # is exact for them), and the chip serves 54.5 G such random requests per second when a kernel does
+                # nothing else (read_gather8 over a 1 GiB table, profiles/r02/pmc_calibration_kernel_stats.csv): THAT
+                # is the ceiling of this kernel, not the 8 TB/s of streamed bytes
+                leg[f"B{B}"]["roofline"]["sector_requests"] = {
+                    "per_launch": int(tr / 64), "achieved_G_s": round(tr / 64 / t_k / 1e9, 1), "peak_G_s": 54.5,
+                    "frac": round(tr / 64 / t_k / 54.5e9, 3)}
             leg[f"B{B}"].update(sdf_train_rates(npm, dec, x, steps, warmup))
         out[f"N{n_points}"] = leg
         del npm, dec
@@ -521,7 +541,8 @@ def sdf_pmc_traffic(n_points, B):
     try:
         files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("sdf_pmc_traffic.json"))
         if files:
-            return json.load(open(files[-1])).get(f"N{n_points}_B{B}", {}).get("hbm_bytes_corrected")
+            rec = json.load(open(files[-1])).get(f"N{n_points}_B{B}", {})
+            return rec.get("hbm_bytes_calibrated", rec.get("hbm_bytes_corrected"))
     except Exception:
         pass
     return None

@@ -2,6 +2,10 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic.
 
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json] [sq_counter_collection.csv]
+           ['{"gaussians": 1000000, "width": 1920, "height": 1080, "mode": "surfel"}']
+
+The optional fifth argument records the workload the passes were taken on (`_workload`); bench.py attaches a traffic
+figure to its roofline object only when that record matches the run.
 
 With the optional fourth file (a separate `--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES` pass) the summary also
 holds the vector / scalar / LDS wave-instructions each kernel issued per launch: `valu_insts` / time against the chip's
@@ -9,14 +13,40 @@ vector issue rate (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
 of a VALU-bound kernel.
 
 Counters are in KiB per dispatch.  On gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
-reads (MI355X_MICROARCH.md §HBM): `fetch_bytes_x2` applies that correction; WRITE_SIZE is exact for
-16-B-per-lane streaming stores.  Other access widths are uncalibrated, so both raw and corrected
-figures are kept.  Only this library's kernels are listed."""
+reads (MI355X_MICROARCH.md §HBM): `fetch_bytes_x2` applies that correction and `hbm_bytes_corrected` = 2 x FETCH + WRITE
+is the guide's figure.  The guide leaves other access widths uncalibrated, so profiles/pmc_calib.hip measures them
+(profiles/r02/pmc_calibration.json): FETCH_SIZE counts one 64-B unit per REQUEST, a request covers the 64-B halves
+of one 128-B line a wave instruction needs — streaming reads (every request a whole line): counter = 1/2 of the bytes;
+64-B tile-row pieces and 8-B random probes (half-line requests): counter = the sector bytes exactly; random 48-B records
+(1.25 lines, 1.5 sectors each): counter = 0.83 of the sector bytes; WRITE_SIZE is exact at 32-B granularity for every
+pattern tried.  `FETCH_FACTOR` below holds the factor of the kernels whose reads are NOT streaming (from the mix of
+their algorithmic reads); `hbm_bytes_calibrated` = factor x FETCH + WRITE.  Only this library's kernels are listed."""
 import collections
 import csv
 import json
 import re
 import sys
+
+
+# kernel (short name prefix) -> (fetch factor, why).  Everything else reads wide and coalesced: factor 2.
+FETCH_FACTOR = {
+    # 149 MB of its 199 MB of reads are 64-B tile-row pieces of the pixel planes (exact), the rest 48-B records (1.2)
+    "blend_bwd_kernel": (1.07, "0.66 x tile-row planes (1.0) + 0.34 x 48-B record gathers (1.2)"),
+    "blend_bwd_scan_kernel": (1.07, "as blend_bwd_kernel"),
+    "blend_fwd_tile_kernel": (1.2, "48-B record gathers (1.2); its pixel traffic is writes"),
+    "blend_fwd_wave_kernel": (1.2, "48-B record gathers"),
+    "blend_fwd_seg_kernel": (1.2, "48-B record gathers"),
+    "sdf_forward_kernel": (1.0, "8-B hash probes and 4..32-B row gathers: one half-line request each (exact)"),
+    "qf_forward_kernel": (1.0, "as sdf_forward_kernel"),
+    "knn_search_kernel": (1.0, "as sdf_forward_kernel"),
+}
+
+
+def fetch_factor(name):
+    for k, v in FETCH_FACTOR.items():
+        if name.startswith(k):
+            return v
+    return (2.0, "wide coalesced reads (guide)")
 
 
 def short(name):
@@ -45,7 +75,9 @@ def main():
         fk = sum(f[k]) / len(f[k]) * 1024
         wk = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1) * 1024
         out[name] = {"launches": len(f[k]), "fetch_bytes_raw": int(fk), "fetch_bytes_x2": int(2 * fk),
-                     "write_bytes": int(wk), "hbm_bytes_corrected": int(2 * fk + wk)}
+                     "write_bytes": int(wk), "hbm_bytes_corrected": int(2 * fk + wk),
+                     "fetch_factor": fetch_factor(name)[0], "fetch_factor_why": fetch_factor(name)[1],
+                     "hbm_bytes_calibrated": int(fetch_factor(name)[0] * fk + wk)}
     if len(sys.argv) > 4:
         sq = {c: load(sys.argv[4], c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES")}
         for k in sq["SQ_INSTS_VALU"]:
@@ -57,7 +89,9 @@ def main():
                     out[name][key] = int(sum(vals) / max(len(vals), 1))
     for n, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
         print(f"{n:44s} n={v['launches']:3d} fetch_raw={v['fetch_bytes_raw']/1e6:9.1f} MB  write={v['write_bytes']/1e6:9.1f} MB  "
-              f"corrected={v['hbm_bytes_corrected']/1e6:9.1f} MB")
+              f"x2={v['hbm_bytes_corrected']/1e6:9.1f} MB  calibrated={v['hbm_bytes_calibrated']/1e6:9.1f} MB")
+    if len(sys.argv) > 5:
+        out["_workload"] = json.loads(sys.argv[5])
     if len(sys.argv) > 3:
         json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
