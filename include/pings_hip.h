@@ -202,6 +202,11 @@ typedef struct pings_knn_map {
   const void* compact;           /* optional compact mirror of `table` (pings_knn_compact_build); when
                                     non-NULL the lookups go there (same results, cache resident)  */
   uint32_t compact_mask;         /* entries - 1                                                */
+  const void* blocks;            /* optional cell-block index (pings_knn_blocks_build): block table ...   */
+  const void* block_records;     /* ... its packed 32-byte point records ...                              */
+  const int32_t* blocks_ok;      /* ... and its status word on the device: the kernels take the index only
+                                    when it reads 1 and fall back to `compact` / `table` otherwise        */
+  uint32_t block_mask;           /* block-table entries - 1                                               */
 } pings_knn_map;
 
 /* Compact, cache-resident mirror of the (>= 99 % empty) dense hash table: open addressing over
@@ -212,6 +217,28 @@ typedef struct pings_knn_map {
 PINGS_API size_t pings_knn_compact_entries(int64_t num_points);
 PINGS_API int pings_knn_compact_build(const int64_t* table, int64_t buffer_size, void* compact,
                                       size_t entries, void* stream);
+
+/* Cell-block index: the search-side state of the map re-laid for locality.  The reference's table is keyed by a
+ * hash of the CELL (neural_gaussians.py:1078-1084), so the 81 neighbour cells of a query are 81 unrelated 64-byte
+ * sectors, and every live candidate costs further gathers (position, creation time, masks, local index).  The index
+ * groups 4x4x4 cells into a block {packed block coordinate, 64-bit occupancy, first record} found through a small
+ * open-addressing table, and keeps one 32-byte record per registered point {x, y, z, global index, global2local,
+ * travel distance at creation, free / valid bits}: a query reads ~8 block entries and its ~10 live records instead
+ * of ~120 sectors.  A point is registered iff table[hash(cell(point))] == point, i.e. iff the reference's lookup of
+ * its own cell returns it.  Results equal the table path's exactly when (a) every non-empty table slot holds a
+ * registered point and (b) no two distinct cells closer than the acceptance radius share a slot; the build verifies
+ * (a) on the device and (b) on the host, writes status[0] = 1 only then, and the search kernels test that word.
+ *
+ * `m` carries the tensors to bake: table, buffer_size, neural_points, resolution, max_valid_dist2 and — each
+ * optional, NULL = not baked, a query that needs it must then not pass the index — point_ts_create + travel_dist,
+ * free_mask, valid_mask, global2local.  max_abs_dx = max |neighbor_dx| (host value).  blocks:
+ * pings_knn_blocks_entries(num_points) * 32 bytes; records: max(num_points, 1) * 32 bytes; status: 8 int32
+ * {ok, registered points, non-empty slots, out-of-range blocks, records, 0, 0, 0}.  Rebuild after ANY change of the
+ * baked tensors. */
+PINGS_API size_t pings_knn_blocks_entries(int64_t num_points);
+PINGS_API int pings_knn_blocks_build(const pings_knn_map* m, int64_t num_points, int64_t num_timestamps,
+                                     int32_t max_abs_dx, void* blocks, size_t entries, void* records,
+                                     int32_t* status, void* stream);
 
 /* idx[B,nn_k] (int64, -1 = none; local indices iff global2local != NULL), d2[B,nn_k]
  * (9e3 where idx = -1, :562), nn_counts[B] (int64: valid candidates over all K cells, :557).

@@ -3,6 +3,9 @@
 // top-k of query_feature :544-569), wave reductions and the quaternion helpers.  See knn_sdf.hip for the design notes.
 #pragma once
 #include "common.hpp"
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace pings_knn {
 
@@ -32,6 +35,51 @@ __device__ inline unsigned wave_min_u32_all(unsigned v) {
   v = min(v, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));
   v = min(v, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int CTRL>
+__device__ inline float dpp_movf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// Sums v[0..7] over the 64 lanes with a transposed reduce-scatter (two quad_perm exchange steps 8 -> 4 -> 2 values per
+// lane, one rotate step inside each 16-lane row, two cross-row swaps): ~30 vector ops and a short dependency chain
+// instead of eight 8-step reductions.  Every add is between a pair of partners that both end with the same sum, so
+// the result is bitwise the same in whichever slot a value travels.  Afterwards lane l of every row holds the wave
+// total of slot 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1).
+__device__ inline int reduce8_slot(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+__device__ inline float wave_reduce8(const float (&v)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, m0 = lane & 4;
+  float u[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float send = b0 ? v[k] : v[k + 4];
+    const float keep = b0 ? v[k + 4] : v[k];
+    u[k] = keep + dpp_movf<0xb1>(send);  // quad_perm [1,0,3,2]
+  }
+  float t[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float send = b1 ? u[k] : u[k + 2];
+    const float keep = b1 ? u[k + 2] : u[k];
+    t[k] = keep + dpp_movf<0x4e>(send);  // quad_perm [2,3,0,1]
+  }
+  // lanes {c, c+4, c+8, c+12} of a row (quads m = 0..3) share the slot base and each hold both slots' quad sums;
+  // lane c+4m ends with slot base + (m & 1).  The four quad sums are added as (q_m + q_m+2) + (q_m+1 + q_m+3) — the
+  // same tree whichever quad ends up holding the slot — so a value's total does not depend on the slot it was put in.
+  const float own = m0 ? t[1] : t[0], other = m0 ? t[0] : t[1];
+  const float x2 = own + dpp_movf<0x128>(own);      // row_ror:8: the quad two away wants the same slot
+  const float y2 = other + dpp_movf<0x128>(other);  // this lane's share of the neighbouring quads' slot
+  float r = x2 + dpp_movf<0x124>(y2);               // row_ror:4: a neighbouring quad's pair sum of MY slot
+  {
+    float a = r, b = r;   // inline asm: this hipcc maps both results of the swap builtins to one register
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r = a + b;
+    a = r; b = r;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    r = a + b;
+  }
+  return r;
 }
 
 // (cx*P0 + cy*P1 + cz*P2) % S with the dividend's sign, wrapped to [0, S) — exact.  |x| < 2^53 and
@@ -64,12 +112,46 @@ __device__ inline long long table_lookup(const pings_knn_map& m, long long h) {
   }
 }
 
+// ---- cell-block index (pings_knn_blocks_build; design notes in knn_blocks.hip) --------------------------------------
+// 4x4x4 cells per block.  Block table: open addressing on the packed block coordinate, 32-byte entries; records: the
+// registered points of a block, packed in cell order, 32 bytes each with everything the search tests.
+struct __attribute__((aligned(32))) BlockEntry {
+  unsigned long long key;   // 1 + packed (bx, by, bz), 0 = empty
+  unsigned long long mask;  // occupied cells of the block
+  unsigned base;            // first record of the block
+  unsigned pad[3];
+};
+struct __attribute__((aligned(32))) BlockRec {
+  float x, y, z;   // neural_points[gidx]
+  int gidx;        // row of the global point array
+  int loc;         // global2local[gidx] as baked (== gidx when no global2local was given)
+  float td;        // travel_dist[point_ts_create[gidx]]
+  unsigned flags;  // bit 0: free_gs_mask, bit 1: valid_gs_mask
+  unsigned pad;
+};
+constexpr int BLOCK_COORD_LIMIT = 1 << 20;  // |block coordinate| < 2^20 (cells < 2^22)
+
+__device__ inline bool block_coord_ok(int bx, int by, int bz) {
+  return bx >= -BLOCK_COORD_LIMIT && bx < BLOCK_COORD_LIMIT && by >= -BLOCK_COORD_LIMIT && by < BLOCK_COORD_LIMIT &&
+         bz >= -BLOCK_COORD_LIMIT && bz < BLOCK_COORD_LIMIT;
+}
+__device__ inline unsigned long long block_key(int bx, int by, int bz) {
+  return 1ull + (((unsigned long long)(unsigned)(bx + BLOCK_COORD_LIMIT) << 42) |
+                 ((unsigned long long)(unsigned)(by + BLOCK_COORD_LIMIT) << 21) |
+                 (unsigned long long)(unsigned)(bz + BLOCK_COORD_LIMIT));
+}
+__device__ inline unsigned block_slot(unsigned long long key, unsigned mask) {
+  return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+__device__ inline unsigned cell_bit(int cx, int cy, int cz) { return (cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4); }
+
 // Per-lane constants of the search, loaded once per wave (not per query).
 struct LaneCtx {
   int dx[2][3];     // cell offsets of this lane's two candidate cells
   bool has[2];      // candidate index < K
   float cur_td;     // travel_dist[cur_ts]
   double inv_S;
+  bool use_blocks;  // the cell-block index is present and was verified exact for this table (uniform)
 };
 
 __device__ inline LaneCtx make_lane_ctx(const pings_knn_map& m, int lane) {
@@ -85,20 +167,27 @@ __device__ inline LaneCtx make_lane_ctx(const pings_knn_map& m, int lane) {
   }
   c.cur_td = m.time_filtering ? m.travel_dist[m.cur_ts] : 0.f;
   c.inv_S = 1.0 / (double)m.buffer_size;
+  c.use_blocks = m.blocks != nullptr && m.blocks_ok != nullptr && *m.blocks_ok == 1;
   return c;
 }
 
-// Search + selection for one query (whole wave).  On return sIdx[i], sD2[i] (i < nn_k) hold the
-// neighbours in order; returns the number of valid candidates over all K cells.
+// A lane's two candidates after every test of the reference (model/neural_gaussians.py:1088-1105, :544-554).
+struct Cand {
+  unsigned key[2];      // fp32 bits of the squared distance (non-negative: ordered as unsigned); ~0 = no such cell
+  long long cidx[2];    // row of the queried tables (local index for a local query), -1 = dropped
+  long long gidx[2];    // row of the global point array, -1 = dropped
+  float px[2], py[2], pz[2];
+};
+
+// Candidates through the reference's table (dense, or its compact mirror).
 //
-// The dependent memory chain is what bounds this kernel, so it is kept to three levels and both of
+// The dependent memory chain is what bounds this path, so it is kept to three levels and both of
 // the lane's candidates walk it together: (1) table probes, (2) everything that depends only on
 // the table entry — position, creation time, free / valid flags, local index — issued as one group
 // with clamped indices, (3) the travel distance of the creation time.  A candidate is dropped if
-// ANY of the reference's tests fails (model/neural_gaussians.py:1088-1105, :544-554), so the tests
-// commute and can be evaluated after the loads.
-__device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
-                                    int lane, long long* sIdx, float* sD2, long long* sGIdx) {
+// ANY of the reference's tests fails, so the tests commute and can be evaluated after the loads.
+__device__ inline void candidates_table(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
+                                        Cand& c) {
   const long long gx = (long long)floorf(qx / m.resolution);
   const long long gy = (long long)floorf(qy / m.resolution);
   const long long gz = (long long)floorf(qz / m.resolution);
@@ -138,16 +227,15 @@ __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, f
   }
 
   // ---- level 2: everything addressed by the table entry, one group of independent loads
-  float px[2], py[2], pz[2];
   int ts[2] = {0, 0};
   unsigned char fr[2] = {0, 0}, va[2] = {1, 1};
   long long loc[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const long long is = tix[r] >= 0 ? tix[r] : 0;
-    px[r] = m.neural_points[3 * is];
-    py[r] = m.neural_points[3 * is + 1];
-    pz[r] = m.neural_points[3 * is + 2];
+    c.px[r] = m.neural_points[3 * is];
+    c.py[r] = m.neural_points[3 * is + 1];
+    c.pz[r] = m.neural_points[3 * is + 2];
     if (m.time_filtering) ts[r] = m.point_ts_create[is];
     if (m.use_free_mask) fr[r] = m.free_mask[is];
     if (m.use_valid_mask) va[r] = m.valid_mask[is];
@@ -160,11 +248,9 @@ __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, f
     td[1] = m.travel_dist[ts[1]];
   }
 
-  unsigned key[2];  // fp32 bits of the squared distance (non-negative: ordered as unsigned); ~0 = taken
-  long long cidx[2], gidx[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const float sx = px[r] - qx, sy = py[r] - qy, sz = pz[r] - qz;
+    const float sx = c.px[r] - qx, sy = c.py[r] - qy, sz = c.pz[r] - qz;
     const float dd = (sx * sx + sy * sy) + sz * sz;
     bool ok = tix[r] >= 0;
     if (m.time_filtering) ok = ok && (fabsf(lc.cur_td - td[r]) < m.diff_travel_dist_local);
@@ -172,25 +258,109 @@ __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, f
     ok = ok && !(m.use_free_mask && fr[r]);
     ok = ok && !(m.use_valid_mask && !va[r]);
     ok = ok && (loc[r] >= 0);
-    cidx[r] = ok ? loc[r] : -1;
-    gidx[r] = ok ? tix[r] : -1;
-    key[r] = lc.has[r] ? __float_as_uint(ok ? dd : INVALID_D2) : 0xFFFFFFFFu;
+    c.cidx[r] = ok ? loc[r] : -1;
+    c.gidx[r] = ok ? tix[r] : -1;
+    c.key[r] = lc.has[r] ? __float_as_uint(ok ? dd : INVALID_D2) : 0xFFFFFFFFu;
   }
-  const int count = __popcll(__ballot(cidx[0] >= 0)) + __popcll(__ballot(cidx[1] >= 0));
+}
+
+// Candidates through the cell-block index: two levels (block entry, record), one 64-B sector per distinct block and
+// per live candidate.  Identical results to candidates_table whenever *m.blocks_ok == 1 (knn_blocks.hip).
+__device__ inline void candidates_blocks(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
+                                         Cand& c) {
+  const float fx = floorf(qx / m.resolution), fy = floorf(qy / m.resolution), fz = floorf(qz / m.resolution);
+  // queries further out than any indexed cell have no candidates (and must not overflow the int cell coordinate)
+  const float lim = (float)(4 * BLOCK_COORD_LIMIT - 256);
+  const bool q_in = fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim;
+  const int gx = q_in ? (int)fx : 0, gy = q_in ? (int)fy : 0, gz = q_in ? (int)fz : 0;
+  const uint4* tab = reinterpret_cast<const uint4*>(m.blocks);
+
+  // ---- level 1: block entries
+  unsigned long long key[2];
+  unsigned slot[2], bit[2];
+  uint4 e[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int cx = gx + lc.dx[r][0], cy = gy + lc.dx[r][1], cz = gz + lc.dx[r][2];
+    key[r] = block_key(cx >> 2, cy >> 2, cz >> 2);
+    bit[r] = cell_bit(cx, cy, cz);
+    slot[r] = block_slot(key[r], m.block_mask);
+  }
+  e[0] = tab[2 * (size_t)slot[0]];
+  e[1] = tab[2 * (size_t)slot[1]];
+  unsigned base[2];
+  bool found[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    unsigned long long k = ((unsigned long long)e[r].y << 32) | e[r].x;
+    while (k != key[r] && k != 0ull) {  // collision chain (load factor <= 0.5 in the worst case, ~0.1 on surfaces)
+      slot[r] = (slot[r] + 1u) & m.block_mask;
+      e[r] = tab[2 * (size_t)slot[r]];
+      k = ((unsigned long long)e[r].y << 32) | e[r].x;
+    }
+    const unsigned long long mask = ((unsigned long long)e[r].w << 32) | e[r].z;
+    found[r] = q_in && lc.has[r] && k == key[r] && ((mask >> bit[r]) & 1ull);
+    const unsigned before = (unsigned)__popcll(mask & ((1ull << bit[r]) - 1ull));
+    base[r] = found[r] ? tab[2 * (size_t)slot[r] + 1].x + before : 0u;
+  }
+  // ---- level 2: records
+  const uint4* recs = reinterpret_cast<const uint4*>(m.block_records);
+  uint4 ra[2], rb[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    ra[r] = recs[2 * (size_t)base[r]];
+    rb[r] = recs[2 * (size_t)base[r] + 1];
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    c.px[r] = __uint_as_float(ra[r].x);
+    c.py[r] = __uint_as_float(ra[r].y);
+    c.pz[r] = __uint_as_float(ra[r].z);
+    const int gi = (int)ra[r].w, li = m.global2local ? (int)rb[r].x : gi;
+    const float td = __uint_as_float(rb[r].y);
+    const unsigned fl = rb[r].z;
+    const float sx = c.px[r] - qx, sy = c.py[r] - qy, sz = c.pz[r] - qz;
+    const float dd = (sx * sx + sy * sy) + sz * sz;
+    bool ok = found[r];
+    if (m.time_filtering) ok = ok && (fabsf(lc.cur_td - td) < m.diff_travel_dist_local);
+    ok = ok && !(dd > m.max_valid_dist2);
+    ok = ok && !(m.use_free_mask && (fl & 1u));
+    ok = ok && !(m.use_valid_mask && !(fl & 2u));
+    ok = ok && (li >= 0);
+    c.cidx[r] = ok ? (long long)li : -1;
+    c.gidx[r] = ok ? (long long)gi : -1;
+    c.key[r] = lc.has[r] ? __float_as_uint(ok ? dd : INVALID_D2) : 0xFFFFFFFFu;
+  }
+}
+
+// Search + selection for one query (whole wave).  On return sIdx[i], sD2[i], sGIdx[i] (i < nn_k) hold the
+// neighbours in order and, when sPos != nullptr, sPos[3 i ..] the global position the distance was measured to;
+// returns the number of valid candidates over all K cells.
+__device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
+                                    int lane, long long* sIdx, float* sD2, long long* sGIdx, float* sPos = nullptr) {
+  Cand c;
+  if (lc.use_blocks) candidates_blocks(m, lc, qx, qy, qz, c);
+  else candidates_table(m, lc, qx, qy, qz, c);
+  const int count = __popcll(__ballot(c.cidx[0] >= 0)) + __popcll(__ballot(c.cidx[1] >= 0));
 
   // nn_k rounds: wave minimum of the distance bits, then the lowest candidate index among the
   // ties (cells 0..63 live in key[0] of lanes 0..63, cells 64.. in key[1])
   for (int i = 0; i < m.nn_k; ++i) {
-    const unsigned best = wave_min_u32_all(min(key[0], key[1]));
-    const unsigned long long b0 = __ballot(key[0] == best);
-    const unsigned long long b1 = __ballot(key[1] == best);
+    const unsigned best = wave_min_u32_all(min(c.key[0], c.key[1]));
+    const unsigned long long b0 = __ballot(c.key[0] == best);
+    const unsigned long long b1 = __ballot(c.key[1] == best);
     const int which = b0 != 0ull ? 0 : 1;
     const int owner = __ffsll((long long)(which ? b1 : b0)) - 1;
     if (lane == owner) {
-      sIdx[i] = which ? cidx[1] : cidx[0];
-      sGIdx[i] = which ? gidx[1] : gidx[0];
+      sIdx[i] = which ? c.cidx[1] : c.cidx[0];
+      sGIdx[i] = which ? c.gidx[1] : c.gidx[0];
       sD2[i] = __uint_as_float(best);
-      if (which) key[1] = 0xFFFFFFFFu; else key[0] = 0xFFFFFFFFu;
+      if (sPos) {
+        sPos[3 * i] = which ? c.px[1] : c.px[0];
+        sPos[3 * i + 1] = which ? c.py[1] : c.py[0];
+        sPos[3 * i + 2] = which ? c.pz[1] : c.pz[0];
+      }
+      if (which) c.key[1] = 0xFFFFFFFFu; else c.key[0] = 0xFFFFFFFFu;
     }
   }
   return count;
@@ -217,6 +387,29 @@ __device__ inline void rot_active(const float* q, float vx, float vy, float vz, 
 }
 
 
+// Row `lane` of W1[H][IN] into this lane's registers THROUGH LDS.  Read straight from global memory the 64 rows of
+// a wave are 64 different lines per load instruction: IN instructions x 64 requests per wave, which at one query per
+// wave (B = 16,384) cost more than the query.  Here the workgroup copies the matrix with coalesced row reads, then
+// every lane reads its row from LDS at an odd stride (conflict-free).  `stage` holds 64 * IN_PAD floats and is free for
+// other use after the call; every thread of the workgroup must call (two barriers inside).
+template <int IN_PAD>
+__device__ inline void load_w1_rows(const float* __restrict__ W1, int IN, int H, float* stage, float (&w1)[IN_PAD],
+                                    float& wn0, float& wn1, float& wn2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int stride = ((IN & 1) || IN + 1 > IN_PAD) ? IN : IN + 1;
+  for (int h = wave; h < H; h += nw)
+    for (int c = lane; c < IN; c += 64) stage[h * stride + c] = W1[h * IN + c];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IN_PAD; ++i) w1[i] = (lane < H && i < IN) ? stage[lane * stride + i] : 0.f;
+  // the three direction-input weights (columns IN-3 .. IN-1) once more as scalars: indexing w1[] with the runtime
+  // feature count would send the array to scratch
+  wn0 = lane < H ? stage[lane * stride + IN - 3] : 0.f;
+  wn1 = lane < H ? stage[lane * stride + IN - 2] : 0.f;
+  wn2 = lane < H ? stage[lane * stride + IN - 1] : 0.f;
+  __syncthreads();
+}
+
 inline int check_map(const pings_knn_map* m) {
   PINGS_ARG_CHECK(m != nullptr, "null map");
   PINGS_ARG_CHECK((m->table || m->compact) && m->buffer_size > 0 && m->neural_points && m->neighbor_dx,
@@ -229,14 +422,45 @@ inline int check_map(const pings_knn_map* m) {
   PINGS_ARG_CHECK(!m->use_free_mask || m->free_mask, "use_free_mask without mask");
   PINGS_ARG_CHECK(!m->use_valid_mask || m->valid_mask, "use_valid_mask without mask");
   PINGS_ARG_CHECK(m->resolution > 0.f, "resolution must be positive");
+  PINGS_ARG_CHECK(!m->blocks || (m->block_records && m->blocks_ok && ((m->block_mask & (m->block_mask + 1u)) == 0u)),
+                  "cell-block index needs its records, its status word and a 2^k - 1 mask");
   return PINGS_OK;
 }
 
-inline unsigned grid_for(long long B) {
+// Workgroups of a wave-per-query kernel: ONE resident round (what the occupancy calculator says fits on the chip at
+// once), the waves loop over the remaining queries.  Measured on the fused SDF forward (1M points): B = 16,384 0.066 ->
+// 0.047 ms, B = 131,072 0.310 -> 0.268 ms against a fixed 8,192-workgroup grid — the per-wave prologue (decoder weights,
+// lane constants) is paid once per resident wave, and a second, nearly empty round is the worst case.
+// PINGS_KNN_GRID_CAP overrides (A/B runs).
+// The search-only kernels (knn_search, query_feature forward) have next to no prologue and measured the other way
+// round (1M points, B = 131,072: 0.105 ms with 8,192 short-lived workgroups, 0.134 ms with one resident round): they
+// pass kernel = nullptr and get the fixed 8,192 cap.
+inline unsigned grid_for(long long B, const void* kernel = nullptr) {
   const long long blocks = (B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  const long long cap = 256LL * 8 * 4;  // 256 CUs x 8 blocks; waves loop over the rest
+  if (kernel == nullptr) return (unsigned)(blocks < 8192 ? blocks : 8192);
+  static const long long env_cap = [] {
+    const char* e = getenv("PINGS_KNN_GRID_CAP");
+    return e ? atoll(e) : 0LL;
+  }();
+  long long cap = env_cap;
+  if (cap <= 0) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, long long> resident;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = resident.find(kernel);
+    if (it == resident.end()) {
+      long long v = 256LL * 4;
+      int dev = 0, cus = 0, per = 0;
+      if (kernel && hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 64 * WAVES_PER_BLOCK, 0) == hipSuccess &&
+          cus > 0 && per > 0)
+        v = (long long)cus * per;
+      it = resident.emplace(kernel, v).first;
+    }
+    cap = it->second;
+  }
   return (unsigned)(blocks < cap ? blocks : cap);
 }
-
 
 }  // namespace pings_knn

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_search_kernel(
   }
 }
 
-template <int IN_PAD>
+template <int IN_PAD, bool GRAD>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     pings_knn_map m, pings_sdf_decoder dec, const float* __restrict__ features,
     const float* __restrict__ points, const float* __restrict__ orientations,
@@ -64,26 +64,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
   __shared__ __attribute__((aligned(16))) float sIn[WAVES_PER_BLOCK][MAX_NNK][IN_PAD];
   __shared__ float sVec[WAVES_PER_BLOCK][MAX_NNK][4];  // x - p_j w.r.t. the searched (global) point: d(d2)/dx
   __shared__ float sS[WAVES_PER_BLOCK][MAX_NNK];       // per-neighbour prediction / projection
+  __shared__ float sPos[WAVES_PER_BLOCK][MAX_NNK * 3]; // the searched (global) positions, from the search itself
+  __shared__ float sGn[WAVES_PER_BLOCK][8][4];         // per-neighbour gradient w.r.t. the direction input
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int F = dec.feat_dim, IN = F + 3, Hd = dec.hidden, nnk = m.nn_k;
   // this lane's hidden unit: weights stay in registers across queries
   float w1[IN_PAD];
   float b1 = 0.f, w2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < IN_PAD; ++i) w1[i] = (lane < Hd && i < IN) ? dec.W1[lane * IN + i] : 0.f;
-  // direction-input weights of this unit (columns F..F+2), kept separately for the gradient
-  const float w1n0 = lane < Hd ? dec.W1[lane * IN + F] : 0.f;
-  const float w1n1 = lane < Hd ? dec.W1[lane * IN + F + 1] : 0.f;
-  const float w1n2 = lane < Hd ? dec.W1[lane * IN + F + 2] : 0.f;
+  float w1n0, w1n1, w1n2;  // direction-input weights of this unit (columns F..F+2), kept separately for the gradient
+  load_w1_rows<IN_PAD>(dec.W1, IN, Hd, &sIn[0][0][0], w1, w1n0, w1n1, w1n2);
   if (lane < Hd) { b1 = dec.b1[lane]; w2 = dec.W2[lane]; }
   const float b2 = dec.b2[0];
 
   const LaneCtx lc = make_lane_ctx(m, lane);
+  // this lane's (neighbour, 16-byte column) pairs of the feature gather, fixed across queries
+  const bool f_vec = (F & 3) == 0 && ((reinterpret_cast<uintptr_t>(features) & 15u) == 0);
+  const int F4 = F >> 2;
+  int f_mm[2] = {-1, -1}, f_c4[2] = {0, 0};
+  if (f_vec)
+    for (int r = 0; r < 2; ++r) {
+      const int e = lane + 64 * r;
+      if (e < nnk * F4) { f_mm[r] = e / F4; f_c4[r] = e - f_mm[r] * F4; }
+    }
   const long long nwaves = (long long)gridDim.x * WAVES_PER_BLOCK;
   for (long long q = (long long)blockIdx.x * WAVES_PER_BLOCK + wave; q < B; q += nwaves) {
     const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
-    const int count = knn_one_query(m, lc, qx, qy, qz, lane, sIdx[wave], sD2[wave], sGIdx[wave]);
+    const int count = knn_one_query(m, lc, qx, qy, qz, lane, sIdx[wave], sD2[wave], sGIdx[wave], sPos[wave]);
     __builtin_amdgcn_wave_barrier();
 
     // ---- inverse-distance weights (lane i < nn_k owns neighbour i)
@@ -108,10 +115,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
         vy = qy - points[3 * my_idx + 1];
         vz = qz - points[3 * my_idx + 2];
         if (certainties) cert = certainties[my_idx] * wgt;
-        const long long gi = sGIdx[wave][lane];
-        sVec[wave][lane][0] = qx - m.neural_points[3 * gi];
-        sVec[wave][lane][1] = qy - m.neural_points[3 * gi + 1];
-        sVec[wave][lane][2] = qz - m.neural_points[3 * gi + 2];
+        sVec[wave][lane][0] = qx - sPos[wave][3 * lane];
+        sVec[wave][lane][1] = qy - sPos[wave][3 * lane + 1];
+        sVec[wave][lane][2] = qz - sPos[wave][3 * lane + 2];
       }
       float nx = vx, ny = vy, nz = vz;
       if (after_pgo && my_idx >= 0) rot_passive(orientations + 4 * my_idx, vx, vy, vz, nx, ny, nz);
@@ -122,11 +128,29 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       const float cs = wave_sum_all(cert);
       if (lane == 0) cert_out[q] = cs;
     }
-    // ---- feature rows -> LDS (zeros for missing neighbours)
-    for (int e = lane; e < nnk * F; e += 64) {
-      const int mm = e / F, f = e - mm * F;
-      const long long id = sIdx[wave][mm];
-      sIn[wave][mm][f] = id >= 0 ? features[id * F + f] : 0.f;
+    // ---- feature rows -> LDS (zeros for missing neighbours): 16 bytes per lane when the rows allow it
+    if (f_vec) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (f_mm[r] >= 0) {
+          const long long id = sIdx[wave][f_mm[r]];
+          const float4 v = id >= 0 ? reinterpret_cast<const float4*>(features + id * F)[f_c4[r]]
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(&sIn[wave][f_mm[r]][4 * f_c4[r]]) = v;
+        }
+      for (int e = lane + 128; e < nnk * F4; e += 64) {
+        const int mm = e / F4, c4 = e - mm * F4;
+        const long long id = sIdx[wave][mm];
+        const float4 v = id >= 0 ? reinterpret_cast<const float4*>(features + id * F)[c4]
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&sIn[wave][mm][4 * c4]) = v;
+      }
+    } else {
+      for (int e = lane; e < nnk * F; e += 64) {
+        const int mm = e / F, f = e - mm * F;
+        const long long id = sIdx[wave][mm];
+        sIn[wave][mm][f] = id >= 0 ? features[id * F + f] : 0.f;
+      }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       }
       const float h = fmaxf(pre, 0.f);
       S = dec.sdf_scale * (b2 + wave_sum_all(lane < Hd ? w2 * h : 0.f));
-      if (grad_out && count > 0) {
+      if (GRAD && count > 0) {
         const float gh = (lane < Hd && pre > 0.f) ? w2 : 0.f;   // dS/dpre_j / scale
         // g_in[i] = sum_j W1[j][i] gh_j ; needed: the 3 direction entries and g_in . in_m
         float gn0 = wave_sum_all(w1n0 * gh), gn1 = wave_sum_all(w1n1 * gh),
@@ -180,6 +204,72 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       }
     } else {
       // per-neighbour MLP, then IDW of the predictions (mapper.py:2279)
+      if (nnk <= 8) {
+        // transposed reductions of eight sums at a time instead of one 8-step reduction per sum: without the gradient
+        // all (<= 8) neighbours' output sums in one; with it {output, three direction-input gradients} of two
+        // neighbours per reduction
+        const int slot = reduce8_slot(lane);
+        if (!GRAD) {
+          float hv[8];
+#pragma unroll
+          for (int mm = 0; mm < 8; ++mm) {
+            float pre = b1;
+            if (mm < nnk) {
+#pragma unroll
+              for (int i = 0; i < IN_PAD; i += 4) {   // the row is broadcast from LDS sixteen bytes at a time
+                const float4 t4 = *reinterpret_cast<const float4*>(&sIn[wave][mm][i]);
+                pre = fmaf(w1[i], t4.x, pre);
+                pre = fmaf(w1[i + 1], t4.y, pre);
+                pre = fmaf(w1[i + 2], t4.z, pre);
+                pre = fmaf(w1[i + 3], t4.w, pre);
+              }
+            }
+            hv[mm] = (mm < nnk && lane < Hd) ? w2 * fmaxf(pre, 0.f) : 0.f;
+          }
+          const float tot = wave_reduce8(hv, lane);
+          if (lane < 8) sS[wave][slot] = dec.sdf_scale * (b2 + tot);
+        } else {
+          for (int m0 = 0; m0 < nnk; m0 += 2) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int mm = m0 + j;
+              float pre = b1;
+              if (mm < nnk) {
+#pragma unroll
+                for (int i = 0; i < IN_PAD; i += 4) {
+                  const float4 t4 = *reinterpret_cast<const float4*>(&sIn[wave][mm][i]);
+                  pre = fmaf(w1[i], t4.x, pre);
+                  pre = fmaf(w1[i + 1], t4.y, pre);
+                  pre = fmaf(w1[i + 2], t4.z, pre);
+                  pre = fmaf(w1[i + 3], t4.w, pre);
+                }
+              }
+              const bool on = mm < nnk && lane < Hd;
+              const float gh = (on && pre > 0.f) ? w2 : 0.f;
+              v[4 * j] = on ? w2 * fmaxf(pre, 0.f) : 0.f;
+              v[4 * j + 1] = w1n0 * gh; v[4 * j + 2] = w1n1 * gh; v[4 * j + 3] = w1n2 * gh;
+            }
+            const float tot = wave_reduce8(v, lane);
+            if (lane < 8) {
+              const int mm = m0 + (slot >> 2), c = slot & 3;
+              if (c == 0) sS[wave][mm] = dec.sdf_scale * (b2 + tot);
+              else sGn[wave][mm][c - 1] = tot;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int mm = 0; mm < nnk; ++mm) {
+          const float wm = sW[wave][mm];
+          S = fmaf(wm, sS[wave][mm], S);
+          if (GRAD && sIdx[wave][mm] >= 0) {
+            float gn0 = sGn[wave][mm][0], gn1 = sGn[wave][mm][1], gn2 = sGn[wave][mm][2];
+            if (after_pgo) rot_active(orientations + 4 * sIdx[wave][mm], gn0, gn1, gn2, gn0, gn1, gn2);
+            const float k = wm * dec.sdf_scale;
+            gx = fmaf(k, gn0, gx); gy = fmaf(k, gn1, gy); gz = fmaf(k, gn2, gz);
+          }
+        }
+      } else
       for (int mm = 0; mm < nnk; ++mm) {
         float pre = b1;
 #pragma unroll
@@ -195,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
         sS[wave][mm] = s_m;
         const float wm = sW[wave][mm];
         S = fmaf(wm, s_m, S);
-        if (grad_out && sIdx[wave][mm] >= 0) {
+        if (GRAD && sIdx[wave][mm] >= 0) {
           const float gh = (lane < Hd && pre > 0.f) ? w2 : 0.f;
           float gn0 = wave_sum_all(w1n0 * gh), gn1 = wave_sum_all(w1n1 * gh),
                 gn2 = wave_sum_all(w1n2 * gh);
@@ -204,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
           gx = fmaf(k, gn0, gx); gy = fmaf(k, gn1, gy); gz = fmaf(k, gn2, gz);
         }
       }
-      if (grad_out && count > 0) {
+      if (GRAD && count > 0) {
         __builtin_amdgcn_wave_barrier();
         for (int mm = 0; mm < nnk; ++mm) {
           if (sIdx[wave][mm] < 0) continue;
@@ -218,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     }
     if (lane == 0) {
       sdf_out[q] = S;
-      if (grad_out) { grad_out[3 * q] = gx; grad_out[3 * q + 1] = gy; grad_out[3 * q + 2] = gz; }
+      if (GRAD) { grad_out[3 * q] = gx; grad_out[3 * q + 1] = gy; grad_out[3 * q + 2] = gz; }
       if (cnt_out) cnt_out[q] = count;
       if (std_out) {
         // spread of the per-neighbour predictions, sqrt(sum_m w_m (s_m - S)^2) (utils/tracker.py:303-308);
@@ -309,15 +399,17 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope ps("sdf_forward", st);
   const int in_dim = dec->feat_dim + 3;
-#define PINGS_SDF_LAUNCH(PAD)                                                                          \
-  hipLaunchKernelGGL(sdf_forward_kernel<PAD>, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \
+#define PINGS_SDF_LAUNCH_G(PAD, G)                                                                          \
+  hipLaunchKernelGGL((sdf_forward_kernel<PAD, G>), dim3(grid_for(B, (const void*)sdf_forward_kernel<PAD, G>)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \
                      *dec, features, points, orientations, certainties, (int)after_pgo, queries,       \
                      (long long)B, sdf, grad_x, (long long*)nn_counts, certainty, (long long*)idx_out, w_out, sdf_std, \
                      (long long*)gidx_out)
+#define PINGS_SDF_LAUNCH(PAD) do { if (grad_x) PINGS_SDF_LAUNCH_G(PAD, true); else PINGS_SDF_LAUNCH_G(PAD, false); } while (0)
   if (in_dim <= 12) PINGS_SDF_LAUNCH(12);
   else if (in_dim <= 36) PINGS_SDF_LAUNCH(36);
   else PINGS_SDF_LAUNCH(64);
 #undef PINGS_SDF_LAUNCH
+#undef PINGS_SDF_LAUNCH_G
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

@@ -26,6 +26,7 @@
 // Everything is fp32 VALU work at ~1,000 wave-instructions per query; the gather + MFMA pipeline of round 1 needed
 // the [B k, F+3] input rows and their gradients materialised in HBM and three more launches.
 // Bitwise reproducible: no float atomics, fixed summation orders.
+#include <algorithm>
 #include "knn_common.hpp"
 #include "row_scatter.hpp"
 
@@ -75,16 +76,13 @@ __global__ __launch_bounds__(64 * WPB, IN_PAD <= 36 ? 3 : 2) void sdf_grad_kerne
   const bool wf = a.weighted_first != 0;
   float w1[IN_PAD], gW1[IN_PAD];
   float b1 = 0.f, w2 = 0.f, gb1 = 0.f, gW2 = 0.f, gb2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < IN_PAD; ++i) {
-    w1[i] = (lane < H && i < IN) ? a.W1[lane * IN + i] : 0.f;
-    gW1[i] = 0.f;
-  }
-  if (lane < H) { b1 = a.b1[lane]; w2 = a.W2[lane]; }
   // the three direction-input weights of this unit and their gradient accumulators are kept apart: F is a runtime
   // value, and indexing the register arrays with it would send them to scratch
-  const float w1n0 = lane < H ? a.W1[lane * IN + F] : 0.f, w1n1 = lane < H ? a.W1[lane * IN + F + 1] : 0.f,
-              w1n2 = lane < H ? a.W1[lane * IN + F + 2] : 0.f;
+  float w1n0, w1n1, w1n2;
+  load_w1_rows<IN_PAD>(a.W1, IN, H, &sIn[0][0][0], w1, w1n0, w1n1, w1n2);
+#pragma unroll
+  for (int i = 0; i < IN_PAD; ++i) gW1[i] = 0.f;
+  if (lane < H) { b1 = a.b1[lane]; w2 = a.W2[lane]; }
   float gWn0 = 0.f, gWn1 = 0.f, gWn2 = 0.f;
   for (int e = threadIdx.x; e < 64 * FP; e += 64 * WPB) {
     const int h = e / FP, c = e - h * FP;
@@ -358,7 +356,13 @@ int run(bool second, const pings_sdf_decoder* dec, const float* features, int64_
   hipStream_t st = pings::as_stream(stream);
   const int F = dec->feat_dim, H = dec->hidden, IN = F + 3;
   Scratch s = carve(scratch, B, nn_k, F, H, feature_rows);
-  const int nblocks = grad_blocks(B);
+  // one resident round (knn_common.hpp grid_for); grad_blocks(B) is what the scratch was sized for
+  const void* kfn = nullptr;
+  if (IN <= 12) kfn = second ? (const void*)sdf_grad_kernel<12, true> : (const void*)sdf_grad_kernel<12, false>;
+  else if (IN <= 20) kfn = second ? (const void*)sdf_grad_kernel<20, true> : (const void*)sdf_grad_kernel<20, false>;
+  else if (IN <= 36) kfn = second ? (const void*)sdf_grad_kernel<36, true> : (const void*)sdf_grad_kernel<36, false>;
+  else kfn = second ? (const void*)sdf_grad_kernel<64, true> : (const void*)sdf_grad_kernel<64, false>;
+  const int nblocks = std::max(1, std::min(grad_blocks(B), (int)grid_for(B > 0 ? B : 1, kfn)));
   const int PSZ = H * (IN + 2) + 1;
   GradArgs a;
   a.W1 = dec->W1; a.b1 = dec->b1; a.W2 = dec->W2;

@@ -18,6 +18,7 @@ is the whole integration.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -34,6 +35,7 @@ class _CKnnMap(C.Structure):
         ("global2local", C.c_void_p), ("neighbor_dx", C.c_void_p), ("K", C.c_int32), ("nn_k", C.c_int32),
         ("resolution", C.c_float), ("max_valid_dist2", C.c_float),
         ("compact", C.c_void_p), ("compact_mask", C.c_uint32),
+        ("blocks", C.c_void_p), ("block_records", C.c_void_p), ("blocks_ok", C.c_void_p), ("block_mask", C.c_uint32),
     ]
 
 
@@ -79,6 +81,10 @@ def _declare(L):
     L.pings_knn_compact_entries.argtypes = [C.c_int64]
     L.pings_knn_compact_build.restype = C.c_int
     L.pings_knn_compact_build.argtypes = [vp, C.c_int64, vp, C.c_size_t, vp]
+    L.pings_knn_blocks_entries.restype = C.c_size_t
+    L.pings_knn_blocks_entries.argtypes = [C.c_int64]
+    L.pings_knn_blocks_build.restype = C.c_int
+    L.pings_knn_blocks_build.argtypes = [C.POINTER(_CKnnMap), C.c_int64, C.c_int64, C.c_int32, vp, C.c_size_t, vp, vp, vp]
     L.pings_sdf_forward.restype = C.c_int
     L.pings_sdf_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CDecoder), vp, vp, vp, vp, C.c_int32, vp,
                                     C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -114,6 +120,81 @@ def _dx32(npm):
 
 
 USE_COMPACT_TABLE = True  # set False to read the reference's dense table directly (identical results)
+# Which search-side layout the kernels read: "blocks" = the cell-block index (pings_knn_blocks_build; falls back to the
+# table on the device if its exactness conditions do not hold), "table" = the reference's table / its compact mirror.
+# All give identical results; PINGS_KNN_INDEX selects for A/B runs and the tests cover both.
+KNN_INDEX = os.environ.get("PINGS_KNN_INDEX", "blocks")
+
+
+def _max_abs_dx(npm) -> int:
+    """max |neighbor_dx| as a host value (one read-back per neighbourhood tensor, cached on the object)."""
+    dx = npm.neighbor_dx
+    cache = getattr(npm, "_pings_dxmax", None)
+    if cache is None or cache[0] is not dx:
+        _lib.note_sync("knn_neighbourhood_extent")
+        cache = (dx, int(dx.abs().max().item()) if dx.numel() else 0)
+        npm._pings_dxmax = cache
+    return cache[1]
+
+
+class _BlockIndex:
+    __slots__ = ("key", "blocks", "records", "status", "mask", "baked", "keep")
+
+
+def _tensor_key(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+
+def _block_index(npm):
+    """The cell-block index of the map's search-side tensors (csrc/knn_blocks.hip), rebuilt whenever any of them
+    changes: identity, shape and torch's in-place version counter of every baked tensor, plus the generation
+    `neural_map.update` bumps after HIP kernels wrote through raw pointers."""
+    table, pts = npm.buffer_pt_index, npm.neural_points
+    N = int(pts.shape[0])
+    opt = {n: getattr(npm, n, None) for n in ("point_ts_create", "travel_dist", "free_gs_mask", "valid_gs_mask",
+                                              "global2local")}
+    for n, t in list(opt.items()):
+        if not torch.is_tensor(t) or not t.is_cuda:
+            opt[n] = None
+    ts, td = opt["point_ts_create"], opt["travel_dist"]
+    if ts is None or td is None or ts.shape[0] < N or td.numel() == 0:
+        ts = td = None
+    free = opt["free_gs_mask"] if opt["free_gs_mask"] is not None and opt["free_gs_mask"].shape[0] >= N else None
+    valid = opt["valid_gs_mask"] if opt["valid_gs_mask"] is not None and opt["valid_gs_mask"].shape[0] >= N else None
+    g2l = opt["global2local"] if opt["global2local"] is not None and opt["global2local"].shape[0] >= N else None
+    key = (_tensor_key(table), _tensor_key(pts), _tensor_key(ts), _tensor_key(td), _tensor_key(free),
+           _tensor_key(valid), _tensor_key(g2l), getattr(npm, "_pings_table_gen", 0), float(npm.resolution),
+           float(npm.max_valid_dist2), id(npm.neighbor_dx))
+    cache = getattr(npm, "_pings_blocks", None)
+    if cache is not None and cache.key == key:
+        return cache
+    L = _L()
+    dev = pts.device
+    bi = _BlockIndex()
+    bi.key = key
+    entries = L.pings_knn_blocks_entries(N)
+    bi.blocks = torch.empty(entries * 4, dtype=torch.int64, device=dev)
+    bi.records = torch.empty(max(N, 1) * 4, dtype=torch.int64, device=dev)
+    bi.status = torch.empty(8, dtype=torch.int32, device=dev)
+    bi.mask = entries - 1
+    bi.baked = dict(ts=ts is not None, free=free is not None, valid=valid is not None, g2l=g2l is not None)
+    keep = [table.contiguous(), pts.contiguous()]
+    ts32 = ts.to(torch.int32).contiguous() if ts is not None else None
+    td32 = td.to(torch.float32).contiguous() if td is not None else None
+    fr8 = _as_u8(free) if free is not None else None
+    va8 = _as_u8(valid) if valid is not None else None
+    g2lc = g2l.to(torch.int64).contiguous() if g2l is not None else None
+    keep += [ts32, td32, fr8, va8, g2lc]
+    m = _CKnnMap(keep[0].data_ptr(), int(table.shape[0]), keep[1].data_ptr(), _lib.ptr(ts32), _lib.ptr(td32), 0, 0, 0.0,
+                 _lib.ptr(fr8), _lib.ptr(va8), 0, 0, _lib.ptr(g2lc), None, 0, 0, float(npm.resolution),
+                 float(npm.max_valid_dist2), None, 0, None, None, None, 0)
+    st = L.pings_knn_blocks_build(C.byref(m), N, int(td32.numel()) if td32 is not None else 0, _max_abs_dx(npm),
+                                  bi.blocks.data_ptr(), entries, bi.records.data_ptr(), bi.status.data_ptr(),
+                                  _lib.stream_ptr(dev))
+    _lib.check(st, "pings_knn_blocks_build")
+    bi.keep = None  # the build has been enqueued on the stream the tensors live on; nothing of `keep` is read later
+    npm._pings_blocks = bi
+    return bi
 
 
 def _compact_table(npm):
@@ -162,7 +243,14 @@ class _MapArgs:
         valid = _as_u8(npm.valid_gs_mask) if use_valid else None
         g2l = npm.global2local.contiguous() if query_locally else None
         dx = _dx32(npm)
-        comp = _compact_table(npm) if USE_COMPACT_TABLE else None
+        blk = None
+        if KNN_INDEX == "blocks" and table.shape[0] < (1 << 31):
+            blk = _block_index(npm)
+            b = blk.baked
+            if (time_filtering and not b["ts"]) or (use_free and not b["free"]) or (use_valid and not b["valid"]) or \
+                    (query_locally and not b["g2l"]):
+                blk = None
+        comp = _compact_table(npm) if (USE_COMPACT_TABLE and blk is None) else None
         self.c = _CKnnMap(
             k(table.contiguous()), int(table.shape[0]), k(npm.neural_points.contiguous()),
             k(ts.contiguous()) if ts is not None else None, k(td) if td is not None else None,
@@ -170,7 +258,9 @@ class _MapArgs:
             k(free) if free is not None else None, k(valid) if valid is not None else None,
             int(use_free), int(use_valid), k(g2l) if g2l is not None else None, k(dx), int(dx.shape[0]),
             _nn_k(npm), float(npm.resolution), float(npm.max_valid_dist2),
-            k(comp) if comp is not None else None, int(comp.shape[0] - 1) if comp is not None else 0)
+            k(comp) if comp is not None else None, int(comp.shape[0] - 1) if comp is not None else 0,
+            k(blk.blocks) if blk is not None else None, k(blk.records) if blk is not None else None,
+            k(blk.status) if blk is not None else None, int(blk.mask) if blk is not None else 0)
         self.device = dev
         self.nn_k = _nn_k(npm)
 

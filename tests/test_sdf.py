@@ -510,3 +510,103 @@ def test_hip_fused_mapper_sdf_double_backward_matches_reference_golden(golden_di
                      for i in range(3)], 1)
     assert rel_err(gn, ref) <= 1e-3          # difference quotient of fp32 values: cancellation
     torch.autograd.grad(gn.square().sum(), params)
+
+
+# ------------------------------------------------------------------ cell-block index (csrc/knn_blocks.hip)
+def _search_all_modes(cpu, gpu, x, hnp):
+    out = []
+    for local, meas, val in [(True, True, False), (False, True, True), (False, False, False), (True, False, True)]:
+        ref = cpu.search_topk(x, query_locally=local, use_only_measured_points=meas, use_only_valid_points=val)
+        got = hnp.radius_neighborhood_topk(gpu, x.cuda(), time_filtering=cpu.temporal_local_map_on and local,
+                                           use_only_measured_points=meas, use_only_valid_points=val,
+                                           query_locally=local)
+        out.append((ref, got))
+    return out
+
+
+def _assert_search_equal(pairs):
+    for (ri, rd, rc), (hi, hd, hc) in pairs:
+        assert torch.equal(hc.cpu(), rc) and torch.equal(hi.cpu(), ri) and torch.equal(hd.cpu(), rd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index", ["blocks", "table"])
+@pytest.mark.parametrize("name", CASES)
+def test_hip_search_layouts_give_the_reference_neighbours(golden_dir, name, index, monkeypatch):
+    """Both search-side layouts (cell-block index, the reference's table) against the oracle on the reference's
+    own maps: indices, order, distances and counts bit for bit, in all four mask / local modes."""
+    from pings_amd import neural_points as hnp
+
+    monkeypatch.setattr(hnp, "KNN_INDEX", index)
+    st = load(golden_dir, name)
+    cpu, gpu = sdf_cpu.NeuralPointMap(st), _gpu_map(st)
+    _assert_search_equal(_search_all_modes(cpu, gpu, T(st["x"]), hnp))
+    if index == "blocks":
+        status = hnp._block_index(gpu).status.cpu().tolist()
+        assert status[0] == 1 and status[1] == status[2] == status[4] and status[3] == 0
+
+
+@pytest.mark.gpu
+def test_block_index_masks_random_and_stale(monkeypatch):
+    """Random free / valid masks, a partial local map and a time window on a synthetic map; then in-place changes of
+    the baked tensors must be seen by the next query (the index is keyed on torch's version counters)."""
+    from pings_amd import neural_points as hnp
+
+    monkeypatch.setattr(hnp, "KNN_INDEX", "blocks")
+    st, _ = sdf_cpu.synthetic_map(20000, seed=3)
+    n = st["neural_points"].shape[0]
+    rng = np.random.default_rng(0)
+    st["free_gs_mask"] = rng.random(n) < 0.2
+    st["valid_gs_mask"] = rng.random(n) < 0.8
+    g2l = np.full(n + 1, -1, np.int64)
+    keep = np.flatnonzero(rng.random(n) < 0.7)
+    g2l[keep] = np.arange(keep.shape[0])
+    st["global2local"] = g2l
+    st["point_ts_create"] = rng.integers(0, 50, n).astype(np.int32)
+    st["travel_dist"] = np.cumsum(rng.random(50)).astype(np.float32)
+    st["cur_ts"], st["diff_travel_dist_local"], st["temporal_local_map_on"] = 49, 12.0, True
+    cpu, gpu = sdf_cpu.NeuralPointMap({**st}), _gpu_map({**st})
+    assert cpu.temporal_local_map_on
+    x = sdf_cpu.synthetic_queries(st, 3000)
+    x = torch.cat([x, torch.tensor([[1e7, 0, 0], [-3e6, 2e6, 5.0], [0, 0, 1e4]])])   # far outside any cell
+    _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
+    assert hnp._block_index(gpu).status.cpu().tolist()[0] == 1
+    first = hnp._block_index(gpu)
+    # in-place edits of baked tensors, mirrored on the oracle's copy
+    flip = torch.from_numpy(rng.random(n) < 0.3)
+    cpu.valid_gs_mask[flip] = ~cpu.valid_gs_mask[flip]
+    gpu.valid_gs_mask[flip.cuda()] = ~gpu.valid_gs_mask[flip.cuda()]
+    cpu.free_gs_mask[:100] = True
+    gpu.free_gs_mask[:100] = True
+    cpu.global2local[keep[:500]] = -1
+    gpu.global2local[torch.from_numpy(keep[:500]).cuda()] = -1
+    _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
+    assert hnp._block_index(gpu) is not first
+
+
+@pytest.mark.gpu
+def test_block_index_refuses_tables_it_cannot_mirror(monkeypatch):
+    """(b) a 76,273-slot table: cells (2, 1, -2) apart share a slot (2 P0 + P1 - 2 P2 = 76,273), the host check fails
+    (a 20,011-slot table, by contrast, only collides far-away cells and IS mirrored); (a) a slot holding a point of another
+    cell: registered points != non-empty slots.  status[0] stays 0 and the kernels answer from the table — still the
+    oracle's neighbours."""
+    from pings_amd import neural_points as hnp
+
+    monkeypatch.setattr(hnp, "KNN_INDEX", "blocks")
+    for size, ok in ((76273, 0), (20011, 1)):
+        st, _ = sdf_cpu.synthetic_map(3000, buffer_size=size)
+        cpu, gpu = sdf_cpu.NeuralPointMap({**st}), _gpu_map({**st})
+        x = sdf_cpu.synthetic_queries(st, 1000)
+        _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
+        assert hnp._block_index(gpu).status.cpu().tolist()[0] == ok
+
+    st, _ = sdf_cpu.synthetic_map(5000, seed=9)
+    cpu, gpu = sdf_cpu.NeuralPointMap({**st}), _gpu_map({**st})
+    # the slot of point 10's cell now holds its neighbour in the list, point 11 (close enough to pass the distance test)
+    slot10 = int((cpu.buffer_pt_index == 10).nonzero()[0, 0])
+    cpu.buffer_pt_index[slot10] = 11
+    gpu.buffer_pt_index[slot10] = 11
+    x = torch.cat([sdf_cpu.synthetic_queries(st, 1000), cpu.neural_points[8:14] + 0.01])
+    _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
+    status = hnp._block_index(gpu).status.cpu().tolist()
+    assert status[0] == 0 and status[1] == status[2] - 1
