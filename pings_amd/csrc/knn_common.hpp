@@ -333,16 +333,12 @@ __device__ inline void candidates_blocks(const pings_knn_map& m, const LaneCtx& 
   }
 }
 
-// Search + selection for one query (whole wave).  On return sIdx[i], sD2[i], sGIdx[i] (i < nn_k) hold the
-// neighbours in order and, when sPos != nullptr, sPos[3 i ..] the global position the distance was measured to;
-// returns the number of valid candidates over all K cells.
-__device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
-                                    int lane, long long* sIdx, float* sD2, long long* sGIdx, float* sPos = nullptr) {
-  Cand c;
-  if (lc.use_blocks) candidates_blocks(m, lc, qx, qy, qz, c);
-  else candidates_table(m, lc, qx, qy, qz, c);
+// The nn_k nearest of a lane-distributed candidate set (whole wave).  On return sIdx[i], sD2[i], sGIdx[i] (i < nn_k)
+// hold the neighbours in order and, when sPos != nullptr, sPos[3 i ..] the global position the distance was measured
+// to; returns the number of valid candidates over all K cells.
+__device__ inline int select_topk(const pings_knn_map& m, Cand& c, int lane, long long* sIdx, float* sD2,
+                                  long long* sGIdx, float* sPos) {
   const int count = __popcll(__ballot(c.cidx[0] >= 0)) + __popcll(__ballot(c.cidx[1] >= 0));
-
   // nn_k rounds: wave minimum of the distance bits, then the lowest candidate index among the
   // ties (cells 0..63 live in key[0] of lanes 0..63, cells 64.. in key[1])
   for (int i = 0; i < m.nn_k; ++i) {
@@ -364,6 +360,18 @@ __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, f
     }
   }
   return count;
+}
+
+// Search + selection for one query (whole wave), nothing prefetched.
+__device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
+                                    int lane, long long* sIdx, float* sD2, long long* sGIdx, float* sPos = nullptr) {
+  Cand c;
+  if (lc.use_blocks) {
+    candidates_blocks(m, lc, qx, qy, qz, c);
+  } else {
+    candidates_table(m, lc, qx, qy, qz, c);
+  }
+  return select_topk(m, c, lane, sIdx, sD2, sGIdx, sPos);
 }
 
 // quaternion [w,x,y,z]: returns R(q)^T v  (utils/tools.py:743-751, the "passive" rotation)
@@ -462,5 +470,13 @@ inline unsigned grid_for(long long B, const void* kernel = nullptr) {
   }
   return (unsigned)(blocks < cap ? blocks : cap);
 }
+
+// sdf_fwd_mfma.hip
+bool sdf_forward_mfma_supported(const pings_knn_map* m, const pings_sdf_decoder* dec, const float* features);
+int sdf_forward_mfma_launch(const pings_knn_map* m, const pings_sdf_decoder* dec, const float* features,
+                            const float* points, const float* orientations, const float* certainties,
+                            int32_t after_pgo, const float* queries, int64_t B, float* sdf, float* grad_x,
+                            int64_t* nn_counts, float* certainty, int64_t* idx_out, float* w_out, float* sdf_std,
+                            int64_t* gidx_out, hipStream_t st);
 
 }  // namespace pings_knn

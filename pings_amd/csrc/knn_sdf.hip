@@ -21,6 +21,8 @@
 // Distances are evaluated as ((dx*dx + dy*dy) + dz*dz) without fused multiply-adds
 // (-ffp-contract=off), which reproduces the reference's fp32 values bit for bit, so the
 // neighbour order is index-exact.
+#include <string>
+
 #include "knn_common.hpp"
 
 namespace {
@@ -49,8 +51,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void knn_search_kernel(
   }
 }
 
+#ifndef PINGS_SDF_FWD_WAVES
+#define PINGS_SDF_FWD_WAVES 4   // waves per SIMD the fused forward is compiled for (128 VGPRs)
+#endif
 template <int IN_PAD, bool GRAD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, PINGS_SDF_FWD_WAVES) void sdf_forward_kernel(
     pings_knn_map m, pings_sdf_decoder dec, const float* __restrict__ features,
     const float* __restrict__ points, const float* __restrict__ orientations,
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,
@@ -88,12 +93,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       if (e < nnk * F4) { f_mm[r] = e / F4; f_c4[r] = e - f_mm[r] * F4; }
     }
   const long long nwaves = (long long)gridDim.x * WAVES_PER_BLOCK;
+  // (Measured and dropped: a software pipeline over the wave's queries — coordinates loaded two queries ahead, the
+  // next query's block entries issued during the current decode — 0.262 -> 0.316 ms at B = 131,072: the second
+  // address computation and 13 spilled registers cost more than the hidden round trip saves.)
   for (long long q = (long long)blockIdx.x * WAVES_PER_BLOCK + wave; q < B; q += nwaves) {
     const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
     const int count = knn_one_query(m, lc, qx, qy, qz, lane, sIdx[wave], sD2[wave], sGIdx[wave], sPos[wave]);
     __builtin_amdgcn_wave_barrier();
 
-    // ---- inverse-distance weights (lane i < nn_k owns neighbour i)
+    // ---- this query's dependent gathers, all issued before the first of them is consumed: positions / certainty of
+    // the neighbours, feature rows
     long long my_idx = -1;
     float u = 0.f, my_d2 = INVALID_D2;
     if (lane < nnk) {
@@ -101,6 +110,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       my_d2 = sD2[wave][lane];
       if (my_idx >= 0) u = 1.0f / (my_d2 + 1e-15f);
     }
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, cval = 0.f;
+    if (my_idx >= 0) {
+      p0 = points[3 * my_idx]; p1 = points[3 * my_idx + 1]; p2 = points[3 * my_idx + 2];
+      if (certainties) cval = certainties[my_idx];
+    }
+    float4 fv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (f_vec) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (f_mm[r] >= 0) {
+          const long long id = sIdx[wave][f_mm[r]];
+          if (id >= 0) fv[r] = reinterpret_cast<const float4*>(features + id * F)[f_c4[r]];
+        }
+    }
+    // ---- inverse-distance weights (lane i < nn_k owns neighbour i)
     const float U = wave_sum_all(u);
     const float wgt = (my_idx >= 0) ? u / U : 0.f;
     float cert = 0.f;
@@ -111,10 +135,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
       if (w_out) w_out[q * nnk + lane] = wgt;
       float vx = 0.f, vy = 0.f, vz = 0.f;
       if (my_idx >= 0) {
-        vx = qx - points[3 * my_idx];
-        vy = qy - points[3 * my_idx + 1];
-        vz = qz - points[3 * my_idx + 2];
-        if (certainties) cert = certainties[my_idx] * wgt;
+        vx = qx - p0;
+        vy = qy - p1;
+        vz = qz - p2;
+        cert = cval * wgt;
         sVec[wave][lane][0] = qx - sPos[wave][3 * lane];
         sVec[wave][lane][1] = qy - sPos[wave][3 * lane + 1];
         sVec[wave][lane][2] = qz - sPos[wave][3 * lane + 2];
@@ -132,12 +156,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
     if (f_vec) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        if (f_mm[r] >= 0) {
-          const long long id = sIdx[wave][f_mm[r]];
-          const float4 v = id >= 0 ? reinterpret_cast<const float4*>(features + id * F)[f_c4[r]]
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&sIn[wave][f_mm[r]][4 * f_c4[r]]) = v;
-        }
+        if (f_mm[r] >= 0) *reinterpret_cast<float4*>(&sIn[wave][f_mm[r]][4 * f_c4[r]]) = fv[r];
       for (int e = lane + 128; e < nnk * F4; e += 64) {
         const int mm = e / F4, c4 = e - mm * F4;
         const long long id = sIdx[wave][mm];
@@ -229,32 +248,39 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_kernel(
           const float tot = wave_reduce8(hv, lane);
           if (lane < 8) sS[wave][slot] = dec.sdf_scale * (b2 + tot);
         } else {
-          for (int m0 = 0; m0 < nnk; m0 += 2) {
-            float v[8];
+          // all hidden-layer chains first (eight independent dependency chains, as above), then the reductions
+          float pre[8];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int mm = m0 + j;
-              float pre = b1;
-              if (mm < nnk) {
+          for (int mm = 0; mm < 8; ++mm) {
+            pre[mm] = b1;
+            if (mm < nnk) {
 #pragma unroll
-                for (int i = 0; i < IN_PAD; i += 4) {
-                  const float4 t4 = *reinterpret_cast<const float4*>(&sIn[wave][mm][i]);
-                  pre = fmaf(w1[i], t4.x, pre);
-                  pre = fmaf(w1[i + 1], t4.y, pre);
-                  pre = fmaf(w1[i + 2], t4.z, pre);
-                  pre = fmaf(w1[i + 3], t4.w, pre);
-                }
+              for (int i = 0; i < IN_PAD; i += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&sIn[wave][mm][i]);
+                pre[mm] = fmaf(w1[i], t4.x, pre[mm]);
+                pre[mm] = fmaf(w1[i + 1], t4.y, pre[mm]);
+                pre[mm] = fmaf(w1[i + 2], t4.z, pre[mm]);
+                pre[mm] = fmaf(w1[i + 3], t4.w, pre[mm]);
               }
-              const bool on = mm < nnk && lane < Hd;
-              const float gh = (on && pre > 0.f) ? w2 : 0.f;
-              v[4 * j] = on ? w2 * fmaxf(pre, 0.f) : 0.f;
-              v[4 * j + 1] = w1n0 * gh; v[4 * j + 2] = w1n1 * gh; v[4 * j + 3] = w1n2 * gh;
             }
-            const float tot = wave_reduce8(v, lane);
-            if (lane < 8) {
-              const int mm = m0 + (slot >> 2), c = slot & 3;
-              if (c == 0) sS[wave][mm] = dec.sdf_scale * (b2 + tot);
-              else sGn[wave][mm][c - 1] = tot;
+          }
+#pragma unroll
+          for (int m0 = 0; m0 < 8; m0 += 2) {
+            if (m0 < nnk) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const bool on = m0 + j < nnk && lane < Hd;
+                const float gh = (on && pre[m0 + j] > 0.f) ? w2 : 0.f;
+                v[4 * j] = on ? w2 * fmaxf(pre[m0 + j], 0.f) : 0.f;
+                v[4 * j + 1] = w1n0 * gh; v[4 * j + 2] = w1n1 * gh; v[4 * j + 3] = w1n2 * gh;
+              }
+              const float tot = wave_reduce8(v, lane);
+              if (lane < 8) {
+                const int mm = m0 + (slot >> 2), c = slot & 3;
+                if (c == 0) sS[wave][mm] = dec.sdf_scale * (b2 + tot);
+                else sGn[wave][mm][c - 1] = tot;
+              }
             }
           }
         }
@@ -398,6 +424,14 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
   PINGS_ARG_CHECK(B > 0 && features && points && queries && sdf, "null pointer");
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope ps("sdf_forward", st);
+  // per-neighbour decoder, nn_k <= 8: the matrix-core kernel (sdf_fwd_mfma.hip); PINGS_SDF_FWD=vector keeps this file's
+  static const bool force_vector = [] {
+    const char* e = getenv("PINGS_SDF_FWD");
+    return e && std::string(e) == "vector";
+  }();
+  if (!force_vector && sdf_forward_mfma_supported(m, dec, features))
+    return sdf_forward_mfma_launch(m, dec, features, points, orientations, certainties, after_pgo, queries, B, sdf,
+                                   grad_x, nn_counts, certainty, idx_out, w_out, sdf_std, gidx_out, st);
   const int in_dim = dec->feat_dim + 3;
 #define PINGS_SDF_LAUNCH_G(PAD, G)                                                                          \
   hipLaunchKernelGGL((sdf_forward_kernel<PAD, G>), dim3(grid_for(B, (const void*)sdf_forward_kernel<PAD, G>)), dim3(64 * WAVES_PER_BLOCK), 0, st, *m, \

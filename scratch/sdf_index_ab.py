@@ -19,7 +19,8 @@ for B in (16384, 131072):
     x = bench.sdf_queries(npm, B, dev)
     fwd = lambda: hnp.sdf_fused(npm, dec, x, use_only_measured_points=False)
     srch = lambda: hnp.radius_neighborhood_topk(npm, x, query_locally=True)
-    for name, fn, stage in (("sdf_forward", fwd, "sdf_forward"), ("knn_search", srch, "knn_search")):
+    fwdg = lambda: hnp.sdf_fused(npm, dec, x, need_grad=True, use_only_measured_points=False)
+    for name, fn, stage in (("sdf_forward", fwd, "sdf_forward"), ("sdf_forward+grad", fwdg, "sdf_forward"), ("knn_search", srch, "knn_search")):
         tw = bench._timeit(fn, 30, 5)
         tk = bench._prof_run(L, fn, 20)[stage]
         print(f"  B={B} {name}: kernel {tk:.4f} ms  wall {tw*1e3:.4f} ms  {B/tk/1e3:.1f} Msamples/s (kernel)")
