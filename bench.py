@@ -551,7 +551,8 @@ def sdf_pmc_traffic(n_points, B):
 def sdf_train_rates(npm, dec, x, steps, warmup):
     """Training-step rates on one map / batch: (a) the fused S(x) with its fused first-order backward, (b) the path an
     unmodified mapper reaches — `query_feature` + the decoder in torch autograd (mapper.py:848-866), first order —
-    and (c) the same with the Eikonal term through get_gradient(create_graph=True) (mapper.py:874-875, :1448)."""
+    (c) the same with the Eikonal term through get_gradient(create_graph=True) (mapper.py:874-875, :1448), and
+    (d) as (b) with `Decoder.sdf` bound to the fused MFMA decoder (`pings_amd.decoder.install`)."""
     from types import SimpleNamespace as NS_
 
     from pings_amd import neural_points as hnp
@@ -578,6 +579,14 @@ def sdf_train_rates(npm, dec, x, steps, warmup):
     def dropin():
         return torch.autograd.grad(sdf_of(x).abs().mean(), [feats] + P_)
 
+    def dropin_fused_decoder():
+        from pings_amd import decoder as hdec
+
+        geo, _, w, c, _ = hnp.query_feature(npm, x, accumulate_stability=False, use_only_measured_points=False)
+        s_ = hdec.sdf(dec_t, geo).squeeze(-1)
+        s_ = s_ if wf else (s_ * w.squeeze(-1)).sum(1)
+        return torch.autograd.grad(s_.abs().mean(), [feats] + P_)
+
     def dropin_eikonal():
         xq = x.detach().clone().requires_grad_(True)
         s_ = sdf_of(xq)
@@ -588,7 +597,8 @@ def sdf_train_rates(npm, dec, x, steps, warmup):
     r = {}
     try:
         for name, fn in (("fwd_bwd_fused_Msamples_s", fused), ("fwd_bwd_query_feature_Msamples_s", dropin),
-                         ("fwd_bwd_eikonal_query_feature_Msamples_s", dropin_eikonal)):
+                         ("fwd_bwd_eikonal_query_feature_Msamples_s", dropin_eikonal),
+                         ("fwd_bwd_query_feature_fused_decoder_Msamples_s", dropin_fused_decoder)):
             r[name] = round(B / _timeit(fn, steps, warmup) / 1e6, 2)
     finally:
         npm.local_geo_features = keep

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void d2n_fwd_kernel(D2N a, float* __restrict__
   out[2 * HW + i] = n[2] / nrm * w;
 }
 
-// Pass 1: per centre pixel, dL/d(un-projected point) of the centre and of its four stencil neighbours
-// (15 floats, planar [15][H][W]).
+// Pass 1: per centre pixel, dL/d(un-projected point) of the centre and of its four stencil neighbours, each already
+// chained through the RECEIVING pixel's P = (ax d, ay d, d), i.e. five scalars dL/d(depth) (planar [5][H][W]; the
+// first version sent the 15 vector components and moved 250 MB through HBM at 1080p).
 __global__ __launch_bounds__(256) void d2n_bwd_stencil_kernel(D2N a, const float* __restrict__ g_out,
                                                               float* __restrict__ adj) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
@@ -136,39 +137,44 @@ __global__ __launch_bounds__(256) void d2n_bwd_stencil_kernel(D2N a, const float
   // folded here into d (1 - m_c).  Left separate they are +-1e11 (n = 0 there, so the normalisation divides by its
   // 1e-12 floor) and swallow every other term of that pixel in fp32.
   const bool su = y == 0, sl = x == 0, sb = y == a.H - 1, sr = x == a.W - 1;
+  float to_c = 0.f, to_u = 0.f, to_l = 0.f, to_b = 0.f, to_r = 0.f;
+  const float ax = ((float)x - a.cx) * a.ifx, ay = ((float)y - a.cy) * a.ify;
+  const float axl = ((float)(x - 1) - a.cx) * a.ifx, axr = ((float)(x + 1) - a.cx) * a.ifx;
+  const float ayu = ((float)(y - 1) - a.cy) * a.ify, ayb = ((float)(y + 1) - a.cy) * a.ify;
+  const float rc[3] = {ax, ay, 1.f}, ru[3] = {ax, ayu, 1.f}, rl[3] = {axl, ay, 1.f}, rb[3] = {ax, ayb, 1.f},
+              rr[3] = {axr, ay, 1.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float du = gu[k] * s.mu, dl = gl[k] * s.ml, db = gb[k] * s.mb, dr = gr[k] * s.mr;
     const float other = (su ? 0.f : du) + (sl ? 0.f : dl) + (sb ? 0.f : db) + (sr ? 0.f : dr);
     const float self = (su ? du : 0.f) + (sl ? dl : 0.f) + (sb ? db : 0.f) + (sr ? dr : 0.f);
-    adj[(size_t)(0 + k) * HW + i] = self * (1.f - s.mc) - other * s.mc;  // to the centre's own point
-    adj[(size_t)(3 + k) * HW + i] = su ? 0.f : du;                       // to the upper neighbour's point
-    adj[(size_t)(6 + k) * HW + i] = sl ? 0.f : dl;
-    adj[(size_t)(9 + k) * HW + i] = sb ? 0.f : db;
-    adj[(size_t)(12 + k) * HW + i] = sr ? 0.f : dr;
+    to_c += (self * (1.f - s.mc) - other * s.mc) * rc[k];  // to the centre's own point
+    to_u += (su ? 0.f : du) * ru[k];                        // to the upper neighbour's point
+    to_l += (sl ? 0.f : dl) * rl[k];
+    to_b += (sb ? 0.f : db) * rb[k];
+    to_r += (sr ? 0.f : dr) * rr[k];
   }
+  adj[i] = to_c;
+  adj[HW + i] = to_u;
+  adj[2 * HW + i] = to_l;
+  adj[3 * HW + i] = to_b;
+  adj[4 * HW + i] = to_r;
 }
 
 // Pass 2: every pixel collects what the stencils that reference it sent (its own centre term, and the up / left /
-// bottom / right terms of the pixels whose clamped neighbour it is), then chains through P = (ax d, ay d, d).
+// bottom / right terms of the pixels whose clamped neighbour it is).
 __global__ __launch_bounds__(256) void d2n_bwd_gather_kernel(D2N a, const float* __restrict__ adj,
                                                              float* __restrict__ g_depth) {
   const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (x >= a.W || y >= a.H) return;
   const size_t HW = (size_t)a.H * a.W;
-  float gp[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float v = adj[(size_t)k * HW + (size_t)y * a.W + x];
-    // pixel (x, y) is the UPPER neighbour of (x, y+1), ... (self-references at the border were folded in pass 1)
-    if (y + 1 < a.H) v += adj[(size_t)(3 + k) * HW + (size_t)(y + 1) * a.W + x];
-    if (x + 1 < a.W) v += adj[(size_t)(6 + k) * HW + (size_t)y * a.W + x + 1];       // LEFT neighbour of (x+1, y)
-    if (y >= 1) v += adj[(size_t)(9 + k) * HW + (size_t)(y - 1) * a.W + x];          // BOTTOM neighbour of (x, y-1)
-    if (x >= 1) v += adj[(size_t)(12 + k) * HW + (size_t)y * a.W + x - 1];           // RIGHT neighbour of (x-1, y)
-    gp[k] = v;
-  }
-  const float ax = ((float)x - a.cx) * a.ifx, ay = ((float)y - a.cy) * a.ify;
-  g_depth[(size_t)y * a.W + x] = (gp[0] * ax + gp[1] * ay) + gp[2];
+  float v = adj[(size_t)y * a.W + x];
+  // pixel (x, y) is the UPPER neighbour of (x, y+1), ... (self-references at the border were folded in pass 1)
+  if (y + 1 < a.H) v += adj[HW + (size_t)(y + 1) * a.W + x];
+  if (x + 1 < a.W) v += adj[2 * HW + (size_t)y * a.W + x + 1];       // LEFT neighbour of (x+1, y)
+  if (y >= 1) v += adj[3 * HW + (size_t)(y - 1) * a.W + x];          // BOTTOM neighbour of (x, y-1)
+  if (x >= 1) v += adj[4 * HW + (size_t)y * a.W + x - 1];            // RIGHT neighbour of (x-1, y)
+  g_depth[(size_t)y * a.W + x] = v;
 }
 
 int fill(D2N& a, const float* depth, const float* alpha, const uint8_t* mask, int H, int W, float cx, float cy,
@@ -196,7 +202,7 @@ PINGS_API int pings_depth2normal_forward(const float* depth, const float* alpha,
   return PINGS_OK;
 }
 
-PINGS_API size_t pings_depth2normal_backward_scratch_bytes(int H, int W) { return (size_t)15 * H * W * sizeof(float); }
+PINGS_API size_t pings_depth2normal_backward_scratch_bytes(int H, int W) { return (size_t)5 * H * W * sizeof(float); }
 
 PINGS_API int pings_depth2normal_backward(const float* depth, const float* alpha, const uint8_t* mask, int H, int W,
                                           float cx, float cy, float fx, float fy, float min_alpha,

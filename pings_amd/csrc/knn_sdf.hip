@@ -425,10 +425,8 @@ PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder*
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope ps("sdf_forward", st);
   // per-neighbour decoder, nn_k <= 8: the matrix-core kernel (sdf_fwd_mfma.hip); PINGS_SDF_FWD=vector keeps this file's
-  static const bool force_vector = [] {
-    const char* e = getenv("PINGS_SDF_FWD");
-    return e && std::string(e) == "vector";
-  }();
+  const char* fwd_env = getenv("PINGS_SDF_FWD");   // read per call: the tests switch it in-process
+  const bool force_vector = fwd_env && std::string(fwd_env) == "vector";
   if (!force_vector && sdf_forward_mfma_supported(m, dec, features))
     return sdf_forward_mfma_launch(m, dec, features, points, orientations, certainties, after_pgo, queries, B, sdf,
                                    grad_x, nn_counts, certainty, idx_out, w_out, sdf_std, gidx_out, st);

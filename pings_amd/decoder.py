@@ -38,7 +38,35 @@ def mlp_batch(decoder, features: torch.Tensor) -> torch.Tensor:
 
         l0, lo = decoder.layers[0], decoder.lout
         return _mlp.fused_mlp(features, l0.weight, l0.bias, lo.weight, lo.bias)
-    return decoder.mlp_batch(features)
+    orig = getattr(type(decoder), "_pings_mlp_batch_torch", None)   # set by install(): the class's own method
+    return orig(decoder, features) if orig is not None else decoder.mlp_batch(features)
+
+
+def sdf(decoder, features: torch.Tensor) -> torch.Tensor:
+    """`Decoder.sdf(features)` (model/decoder.py:100-104): `mlp(features).squeeze(1) * sdf_scale` for [N, IN] or
+    [N, K, IN] inputs — the decoder call of the mapper's training / inference loops (utils/mapper.py:537,574,858,1508,
+    2275) — through the fused MFMA kernel pair.  First-order backward in HIP; a recorded backward (create_graph=True,
+    only taken with `numerical_grad: False`) falls to torch ops inside `_FusedMLP.backward`."""
+    if not features.is_cuda:
+        from . import _lib
+
+        raise _lib.PingsHipError("decoder.sdf runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+    if _supported(decoder) and features.shape[0] > 0:
+        from . import mlp as _mlp
+
+        l0, lo = decoder.layers[0], decoder.lout
+        y = _mlp.fused_mlp(features.reshape(-1, features.shape[-1]), l0.weight, l0.bias, lo.weight, lo.bias)
+        return y.view(*features.shape[:-1], y.shape[-1]).squeeze(1) * decoder.sdf_scale
+    return decoder.mlp(features).squeeze(1) * decoder.sdf_scale
+
+
+def install(decoder_cls) -> None:
+    """`Decoder.sdf` and `Decoder.mlp_batch` of the reference class through the fused kernels (the parameters stay
+    the module's own)."""
+    decoder_cls.sdf = sdf
+    if hasattr(decoder_cls, "mlp_batch") and not hasattr(decoder_cls, "_pings_mlp_batch_torch"):
+        decoder_cls._pings_mlp_batch_torch = decoder_cls.mlp_batch
+        decoder_cls.mlp_batch = lambda self, features: mlp_batch(self, features)
 
 
 def mlp_batch_group(decoders, features):

@@ -42,31 +42,45 @@ def supported(IN: int, HID: int, OUT: int) -> bool:
     return 0 < IN <= 64 and HID in (32, 64, 96, 128) and 0 < OUT <= 32
 
 
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
 class _FusedMLP(torch.autograd.Function):
+    """Forward and first-order backward in HIP.  A backward that is itself being recorded (create_graph=True: the
+    Eikonal / consistency terms on dS/dx, utils/mapper.py:1448) is built from torch ops on the ORIGINAL inputs instead,
+    so that autograd can differentiate it once more (relu'' = 0, as torch's own relu)."""
+
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2):
         L = _lib.lib()
         _declare(L)
-        xs = x.detach().to(torch.float32).contiguous()
-        W1c, b1c = W1.detach().to(torch.float32).contiguous(), b1.detach().to(torch.float32).contiguous()
-        W2c, b2c = W2.detach().to(torch.float32).contiguous(), b2.detach().to(torch.float32).contiguous()
+        xs, W1c, b1c, W2c, b2c = _f32c(x), _f32c(W1), _f32c(b1), _f32c(W2), _f32c(b2)
         N, IN = xs.shape
         HID, OUT = W1c.shape[0], W2c.shape[0]
         y = torch.empty(N, OUT, dtype=torch.float32, device=xs.device)
         st = L.pings_mlp_forward(_lib.ptr(xs), N, IN, HID, OUT, _lib.ptr(W1c), _lib.ptr(b1c), _lib.ptr(W2c),
                                  _lib.ptr(b2c), _lib.ptr(y), _lib.stream_ptr(xs.device))
         _lib.check(st, "pings_mlp_forward")
-        ctx.save_for_backward(xs, W1c, b1c, W2c)
+        ctx.save_for_backward(x, W1, b1, W2)      # the inputs themselves (no copies when already fp32 contiguous)
         ctx.need_x = x.requires_grad
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        x, W1, b1, W2 = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            pre = torch.nn.functional.linear(x, W1, b1)
+            mask = (pre > 0).to(pre.dtype)
+            gh = (gy @ W2) * mask
+            gx = gh @ W1 if ctx.need_x else None
+            return gx, gh.t() @ x, gh.sum(0), gy.t() @ (pre * mask), gy.sum(0)
         L = _lib.lib()
-        xs, W1c, b1c, W2c = ctx.saved_tensors
+        xs, W1c, b1c, W2c = _f32c(x), _f32c(W1), _f32c(b1), _f32c(W2)
         N, IN = xs.shape
         HID, OUT = W1c.shape[0], W2c.shape[0]
-        g = gy.detach().to(torch.float32).contiguous()
+        g = _f32c(gy)
         dev = xs.device
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty(N, IN, **f32) if ctx.need_x else None

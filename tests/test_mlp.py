@@ -98,3 +98,60 @@ def test_grouped_decoders_equal_the_single_launches_bit_for_bit():
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
         else:
             assert torch.equal(a, b), i
+
+
+class _TorchDecoder(torch.nn.Module):
+    """The parts of model/decoder.py's Decoder that `sdf` touches (layers / lout / mlp / sdf / sdf_scale)."""
+
+    def __init__(self, IN, HID, scale, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.layers = torch.nn.ModuleList([torch.nn.Linear(IN, HID)])
+        self.lout = torch.nn.Linear(HID, 1)
+        self.use_leaky_relu = False
+        self.sdf_scale = scale
+
+    def mlp(self, features):
+        return self.lout(torch.relu(self.layers[0](features)))
+
+    def sdf(self, features):
+        return self.mlp(features).squeeze(1) * self.sdf_scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4000, 6, 35), (4000, None, 35), (1, 6, 11)])
+def test_decoder_sdf_fused_first_and_second_order_match_torch(shape):
+    """`pings_amd.decoder.sdf` in place of `Decoder.sdf` (model/decoder.py:100-104): values and parameter / input
+    gradients of a plain loss (HIP backward), and of an Eikonal-type loss on d sdf / d input taken with
+    create_graph=True (the recorded backward is built from torch ops), against the module's own torch path."""
+    from pings_amd import decoder as hdec
+
+    N, K, IN = shape
+    dec = _TorchDecoder(IN, 64, 0.37, seed=IN).cuda()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(*((N, K, IN) if K else (N, IN)), generator=g).cuda()
+    w = torch.rand(*feats.shape[:-1], generator=torch.Generator().manual_seed(6)).cuda()
+
+    def run(fn, second):
+        x = feats.clone().requires_grad_(True)
+        s = fn(x)
+        loss = (s.reshape(w.shape) * w).abs().sum()
+        if second:
+            gx = torch.autograd.grad(s.sum(), x, create_graph=True)[0]
+            loss = loss + ((gx[..., -3:].norm(dim=-1) - 1.0) ** 2).sum()
+        return [s.detach(), *torch.autograd.grad(loss, [x, *dec.parameters()])]
+
+    for second in (False, True):
+        ref = run(dec.sdf, second)
+        got = run(lambda x: hdec.sdf(dec, x), second)
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape
+            assert rel_err(a, b) <= 2e-5, (second, rel_err(a, b))
+    # install(): the class method itself is replaced, parameters stay the module's
+    torch_sdf = _TorchDecoder.sdf
+    hdec.install(_TorchDecoder)
+    try:
+        assert _TorchDecoder.sdf is hdec.sdf
+        assert rel_err(dec.sdf(feats), ref[0]) <= 2e-5
+    finally:
+        _TorchDecoder.sdf = torch_sdf

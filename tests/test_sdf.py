@@ -183,6 +183,32 @@ class _Dec:
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
+def test_hip_fused_sdf_vector_and_matrix_core_kernels_agree(golden_dir, name, monkeypatch):
+    """`pings_sdf_forward` has two kernels (csrc/knn_sdf.hip lane-per-hidden-unit, csrc/sdf_fwd_mfma.hip four queries
+    per wave on the matrix cores); PINGS_SDF_FWD=vector forces the first.  Same neighbours, weights and counts bit for
+    bit; SDF, gradient and spread within fp32 summation-order noise of each other (and each within 1e-4 of the
+    reference: the golden test below runs the default, this one checks the forced kernel too)."""
+    from pings_amd import neural_points as hnp
+
+    st = load(golden_dir, name)
+    gpu = _gpu_map(st)
+    x = T(st["x"]).cuda()
+    dec = _Dec(st)
+    out = {}
+    for mode in ("mfma", "vector"):
+        monkeypatch.setenv("PINGS_SDF_FWD", mode)
+        out[mode] = hnp.sdf_fused(gpu, dec, x, need_grad=True, need_certainty=True, need_std=True)
+    for a, b in zip(out["mfma"], out["vector"]):
+        if a.dtype == torch.int64:
+            assert torch.equal(a, b)
+        else:
+            assert rel_err(a, b) <= 2e-5, rel_err(a, b)
+    if "g3_sdf" in st and not gpu.weighted_first:
+        assert rel_err(out["vector"][0], T(st["g3_sdf"])) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
 def test_hip_fused_sdf_matches_reference_golden(golden_dir, name):
     from pings_amd import neural_points as hnp
 
