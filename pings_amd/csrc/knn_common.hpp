@@ -82,6 +82,18 @@ __device__ inline float wave_reduce8(const float (&v)[8], int lane) {
   return r;
 }
 
+// sum over the 8-lane group of a lane (all 8 lanes get it): xor 1, xor 2 inside the quad, then the other quad through
+// row_half_mirror (lane i <-> 7 - i of the 8-lane half row, which holds the other quad's total)
+__device__ inline float group8_sum(float v) {
+  v += dpp_movf<0xb1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_movf<0x4e>(v);   // quad_perm [2,3,0,1]
+  v += dpp_movf<0x141>(v);  // row_half_mirror
+  return v;
+}
+
+// row of a 32x32 MFMA accumulator register: D[rowmap32(reg, lane >> 5)][lane & 31]
+__device__ inline int rowmap32(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
 // (cx*P0 + cy*P1 + cz*P2) % S with the dividend's sign, wrapped to [0, S) — exact.  |x| < 2^53 and
 // S < 2^31, so the quotient estimate from one fp64 division is off by at most one; an int64
 // division (a ~100-instruction software routine on gfx950) is avoided.

@@ -27,6 +27,7 @@
 // the [B k, F+3] input rows and their gradients materialised in HBM and three more launches.
 // Bitwise reproducible: no float atomics, fixed summation orders.
 #include <algorithm>
+#include <string>
 #include "knn_common.hpp"
 #include "row_scatter.hpp"
 
@@ -289,6 +290,270 @@ __global__ __launch_bounds__(64 * WPB, IN_PAD <= 36 ? 3 : 2) void sdf_grad_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// First-order backward of the per-neighbour decoder on the matrix cores (nn_k <= 8, F a power-of-two multiple of 4
+// up to 32): the counterpart of sdf_forward_mfma_kernel.  A wave takes four queries = 32 (query, neighbour) columns:
+//   pre  = [W1 | b1] X                       32x32x2 MFMA, X staged in LDS in operand order (as in the forward)
+//   Gp   = a_n W2[h] 1[pre > 0]              (dL/dpre; a_n = dL/dS scale w_n)   from the accumulator registers
+//   dX^T = W1^T Gp                           MFMA with the Gp ACCUMULATOR as the B operand (its column is on the lane
+//                                            and its rows in the 16 registers: the operand layout in row order
+//                                            rowmap32) -> the feature-gradient rows, 16-byte stores
+//   dW1 += Gp X^T                            MFMA over the columns: Gp takes one trip through LDS (transposed read),
+//                                            X is read from its staging area with the column as k
+//   dW1[:, F..F+2], db1 (= the bias column)  when they do not fit the 32-wide block (F = 32): per-lane FMAs on the
+//                                            transposed Gp against the four tail inputs (LDS broadcast)
+//   dW2 += sum_n a_n relu(pre)               the same transposed trip, summed in the lane
+// The weight-gradient accumulators stay in registers across the wave's queries; one partial per workgroup, summed in
+// fixed order.  ~200 vector instructions per query instead of ~1,100.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int GQ = 4, GNB = 8, GCOLS = GQ * GNB;
+constexpr int GROW = 36;   // row of a transposed 32x32 block in LDS: [k = n & 1][t = n >> 1] + 4 (conflict-free 16-B reads)
+
+template <int IN_PAD>
+__global__ __launch_bounds__(64 * WPB, IN_PAD > 32 ? 2 : 3) void sdf_grad_mfma_kernel(GradArgs a) {
+  constexpr int HALF = IN_PAD / 2, HALF_PAD = (HALF + 3) & ~3, ROW = 2 * HALF_PAD + 4;
+  constexpr bool TAIL = IN_PAD > 32;                       // inputs 32.. (direction + bias column) outside the main block
+  constexpr int XW = GCOLS * ROW > 32 * GROW ? GCOLS * ROW : 32 * GROW;
+  __shared__ __attribute__((aligned(16))) float sX[WPB][XW];
+  __shared__ __attribute__((aligned(16))) float sA[2][HALF_PAD / 4][64][4];   // forward A operand
+  __shared__ __attribute__((aligned(16))) float sWT[2][4][64][4];             // dX A operand: W1[h = rowmap(s)][i = lane]
+  __shared__ __attribute__((aligned(16))) float sTail[WPB][GCOLS][4];         // inputs 32..35 of every column
+  __shared__ float sW2[64];
+  __shared__ int sId[WPB][GCOLS];
+  __shared__ float sRed[WPB][64];
+  static_assert(WPB * XW >= 64 * IN_PAD, "the weight staging area must hold W1");
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int F = a.F, IN = F + 3, H = a.H, nnk = a.nnk;
+  const int r32 = lane & 31, kh = lane >> 5;
+  {
+    float* stage = &sX[0][0];
+    const int stride = IN | 1;
+    for (int h = wave; h < H; h += WPB)
+      for (int c = lane; c < IN; c += 64) stage[h * stride + c] = a.W1[h * IN + c];
+    for (int h = threadIdx.x; h < 64; h += 64 * WPB) sW2[h] = h < H ? a.W2[h] : 0.f;
+    __syncthreads();
+    if (wave < 2) {
+      const int row = wave * 32 + r32;
+      for (int t = 0; t < HALF_PAD; ++t) {
+        const int c = 2 * t + kh;
+        float v = 0.f;
+        if (row < H && t < HALF) v = c < IN ? stage[row * stride + c] : (c == IN ? a.b1[row] : 0.f);
+        sA[wave][t >> 2][lane][t & 3] = v;
+      }
+      for (int s = 0; s < 16; ++s) {
+        const int h = wave * 32 + rowmap32(s, kh);
+        sWT[wave][s >> 2][lane][s & 3] = (h < H && r32 < F) ? stage[h * stride + r32] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  const bool two_blocks = H > 32;
+  const int F4 = F >> 2;
+  const int f4_shift = 31 - __clz(F4);
+  const int n_gather = (GCOLS * F4 + 63) >> 6;
+  float* X = sX[wave];
+  const int j_of = r32 >> 3, mm_of = r32 & 7;
+
+  f32x16 accW1[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) accW1[mb][s] = 0.f;
+  float tailW[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float accW2[2] = {0.f, 0.f};
+  float accB2 = 0.f;
+
+  const long long ngroups = (a.B + GQ - 1) / GQ;
+  const long long nwaves = (long long)gridDim.x * WPB;
+  for (long long g = (long long)blockIdx.x * WPB + wave; g < ngroups; g += nwaves) {
+    // ---- column owner: neighbour, weight, upstream gradient, geometry (lanes 32..63 mirror 0..31)
+    const long long q_mine = g * GQ + j_of;
+    const bool slot_on = mm_of < nnk && q_mine < a.B;
+    long long id = -1;
+    float an = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    if (slot_on) {
+      id = a.idx[q_mine * nnk + mm_of];
+      an = a.dL_dsdf[q_mine] * a.scale * a.w[q_mine * nnk + mm_of];
+      qx = a.queries[3 * q_mine]; qy = a.queries[3 * q_mine + 1]; qz = a.queries[3 * q_mine + 2];
+    }
+    if (lane < GCOLS) sId[wave][r32] = (int)id;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (id >= 0) {
+      const float px = qx - a.points[3 * id], py = qy - a.points[3 * id + 1], pz = qz - a.points[3 * id + 2];
+      nx = px; ny = py; nz = pz;
+      if (a.after_pgo) rot_passive(a.orientations + 4 * id, px, py, pz, nx, ny, nz);
+    } else {
+      an = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < n_gather; ++i) {
+      const int e = lane + 64 * i;
+      if (e < GCOLS * F4) {
+        const int col = e >> f4_shift, c4 = e & (F4 - 1);
+        const int idc = sId[wave][col];
+        const float4 v = idc >= 0 ? reinterpret_cast<const float4*>(a.features + (size_t)idc * F)[c4]
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float2*>(&X[col * ROW + 2 * c4]) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(&X[col * ROW + HALF_PAD + 2 * c4]) = make_float2(v.y, v.w);
+      }
+    }
+    if (lane < GCOLS) {
+      float* row = &X[r32 * ROW];
+      const float tail[4] = {nx, ny, nz, 1.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = F + c;
+        row[(col & 1) * HALF_PAD + (col >> 1)] = tail[c];
+      }
+      for (int col = IN + 1; col < IN_PAD; ++col) row[(col & 1) * HALF_PAD + (col >> 1)] = 0.f;
+      if (TAIL) *reinterpret_cast<float4*>(sTail[wave][r32]) = make_float4(nx, ny, nz, 1.f);
+      if (slot_on) a.keys[q_mine * nnk + mm_of] = id >= 0 ? (uint32_t)id : (uint32_t)a.table_rows;
+      accB2 += an;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- operands out of the staging area: forward B (column r32, k half kh) and dW1 B (column 2t + kh, input r32)
+    float bx[HALF_PAD];
+#pragma unroll
+    for (int t = 0; t < HALF_PAD; t += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(&X[r32 * ROW + kh * HALF_PAD + t]);
+      bx[t] = v.x; bx[t + 1] = v.y; bx[t + 2] = v.z; bx[t + 3] = v.w;
+    }
+    float bxT[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      bxT[t] = r32 < IN_PAD ? X[(2 * t + kh) * ROW + (r32 & 1) * HALF_PAD + (r32 >> 1)] : 0.f;
+    __builtin_amdgcn_wave_barrier();   // the staging area is free from here on (transposes below)
+
+    f32x16 dX = {0};
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      if (mb == 1 && !two_blocks) break;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int t = 0; t < HALF_PAD; t += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sA[mb][t >> 2][lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bx[t], acc, 0, 0, 0);
+        if (t + 1 < HALF) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bx[t + 1], acc, 0, 0, 0);
+        if (t + 2 < HALF) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bx[t + 2], acc, 0, 0, 0);
+        if (t + 3 < HALF) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bx[t + 3], acc, 0, 0, 0);
+      }
+      // Gp = a_n W2 1[pre > 0], R = a_n relu(pre)   (column r32 on the lane, hidden rowmap32(s, kh) in register s)
+      float gp[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) gp[s] = acc[s] > 0.f ? an * sW2[mb * 32 + rowmap32(s, kh)] : 0.f;
+      // dX^T += W1^T Gp  (accumulator layout as the B operand)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(sWT[mb][s4][lane]);
+        dX = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, gp[4 * s4], dX, 0, 0, 0);
+        dX = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, gp[4 * s4 + 1], dX, 0, 0, 0);
+        dX = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, gp[4 * s4 + 2], dX, 0, 0, 0);
+        dX = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, gp[4 * s4 + 3], dX, 0, 0, 0);
+      }
+      // Gp transposed through LDS: lane (h = r32, k half kh) reads Gp[h][n = 2t + kh], t = 0..15
+#pragma unroll
+      for (int s = 0; s < 16; ++s) X[rowmap32(s, kh) * GROW + (r32 & 1) * 16 + (r32 >> 1)] = gp[s];
+      __builtin_amdgcn_wave_barrier();
+      float gt[16];
+#pragma unroll
+      for (int t = 0; t < 16; t += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&X[r32 * GROW + kh * 16 + t]);
+        gt[t] = v.x; gt[t + 1] = v.y; gt[t + 2] = v.z; gt[t + 3] = v.w;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) accW1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[t], bxT[t], accW1[mb], 0, 0, 0);
+      if (TAIL) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float4 x4 = *reinterpret_cast<const float4*>(sTail[wave][2 * t + kh]);
+          tailW[mb][0] = fmaf(gt[t], x4.x, tailW[mb][0]);
+          tailW[mb][1] = fmaf(gt[t], x4.y, tailW[mb][1]);
+          tailW[mb][2] = fmaf(gt[t], x4.z, tailW[mb][2]);
+          tailW[mb][3] = fmaf(gt[t], x4.w, tailW[mb][3]);
+        }
+      }
+      // R the same way, summed over its columns in the lane
+#pragma unroll
+      for (int s = 0; s < 16; ++s) X[rowmap32(s, kh) * GROW + (r32 & 1) * 16 + (r32 >> 1)] = an * fmaxf(acc[s], 0.f);
+      __builtin_amdgcn_wave_barrier();
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; t += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&X[r32 * GROW + kh * 16 + t]);
+        rs += (v.x + v.y) + (v.z + v.w);
+      }
+      accW2[mb] += rs;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- feature-gradient rows: dX^T[i = rowmap32(s, kh)][column r32], four consecutive inputs per 16-byte store
+    if (slot_on) {
+      float* o = a.rows + (size_t)(q_mine * nnk + mm_of) * F;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int i0 = 8 * g4 + 4 * kh;
+        if (i0 < F)
+          *reinterpret_cast<float4*>(o + i0) = make_float4(dX[4 * g4], dX[4 * g4 + 1], dX[4 * g4 + 2], dX[4 * g4 + 3]);
+      }
+    }
+  }
+
+  // ---- parameter gradients: the four waves of the workgroup in wave order, one partial per workgroup
+  const int PSZ = H * (IN + 2) + 1;
+  float* out = a.partials + (size_t)blockIdx.x * PSZ;
+  auto wg_sum = [&](float v) {
+    __syncthreads();
+    sRed[wave][lane] = v;
+    __syncthreads();
+    return ((sRed[0][lane] + sRed[1][lane]) + sRed[2][lane]) + sRed[3][lane];
+  };
+  auto half_sum = [&](float v) {   // the two lane halves hold the even / odd columns' shares of the same hidden unit
+    float x = v, y = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+  };
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float v = wg_sum(accW1[mb][s]);      // dW1aug[h = mb*32 + rowmap32(s, kh)][i = r32]
+      const int h = mb * 32 + rowmap32(s, kh);
+      if (wave == 0 && h < H) {
+        if (r32 < IN) out[h * IN + r32] = v;
+        else if (!TAIL && r32 == IN) out[H * IN + h] = v;   // the bias column is db1
+      }
+    }
+    if (TAIL) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = wg_sum(half_sum(tailW[mb][c]));
+        const int h = mb * 32 + r32;
+        if (wave == 0 && kh == 0 && h < H) {
+          if (c < 3) out[h * IN + 32 + c] = v; else out[H * IN + h] = v;
+        }
+      }
+    }
+    const float v2 = wg_sum(half_sum(accW2[mb]));
+    if (wave == 0 && kh == 0 && mb * 32 + r32 < H) out[H * IN + H + mb * 32 + r32] = v2;
+  }
+  {
+    float v = lane < GCOLS ? accB2 : 0.f;
+    v = wave_sum_all(v);
+    const float s3 = wg_sum(v);
+    if (wave == 0 && lane == 0) out[H * IN + 2 * H] = s3;
+  }
+}
+
+bool grad_mfma_supported(bool second, const pings_sdf_decoder* dec, int nn_k, const float* features, const float* rows) {
+  const int F = dec->feat_dim, F4 = F >> 2;
+  const char* e = getenv("PINGS_SDF_BWD");
+  if (e && std::string(e) == "vector") return false;
+  return !second && !dec->weighted_first && nn_k <= GNB && (F & 3) == 0 && F4 > 0 && (F4 & (F4 - 1)) == 0 && F <= 32 &&
+         dec->hidden <= 64 && ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(rows)) & 15u) == 0;
+}
+
 // out[e] = sum over the per-workgroup partials, one wave per output element: lane l adds partials l, l + 64, ... in
 // order (independent loads, all in flight), the wave then adds its 64 lane sums in a fixed tree: the same bits every
 // run.  dW1 [H, IN] | db1 [H] | dW2 [H] | db2 [1]
@@ -357,12 +622,19 @@ int run(bool second, const pings_sdf_decoder* dec, const float* features, int64_
   const int F = dec->feat_dim, H = dec->hidden, IN = F + 3;
   Scratch s = carve(scratch, B, nn_k, F, H, feature_rows);
   // one resident round (knn_common.hpp grid_for); grad_blocks(B) is what the scratch was sized for
+  const bool mfma = grad_mfma_supported(second, dec, nn_k, features, s.rows);
+  const int need = F + 4;
   const void* kfn = nullptr;
-  if (IN <= 12) kfn = second ? (const void*)sdf_grad_kernel<12, true> : (const void*)sdf_grad_kernel<12, false>;
+  if (mfma) {
+    kfn = need <= 12 ? (const void*)sdf_grad_mfma_kernel<12>
+                     : (need <= 20 ? (const void*)sdf_grad_mfma_kernel<20> : (const void*)sdf_grad_mfma_kernel<36>);
+  } else if (IN <= 12) kfn = second ? (const void*)sdf_grad_kernel<12, true> : (const void*)sdf_grad_kernel<12, false>;
   else if (IN <= 20) kfn = second ? (const void*)sdf_grad_kernel<20, true> : (const void*)sdf_grad_kernel<20, false>;
   else if (IN <= 36) kfn = second ? (const void*)sdf_grad_kernel<36, true> : (const void*)sdf_grad_kernel<36, false>;
   else kfn = second ? (const void*)sdf_grad_kernel<64, true> : (const void*)sdf_grad_kernel<64, false>;
-  const int nblocks = std::max(1, std::min(grad_blocks(B), (int)grid_for(B > 0 ? B : 1, kfn)));
+  const long long work = mfma ? (B + GQ - 1) / GQ : B;   // wave-steps: four queries each on the matrix-core kernel
+  int nblocks = std::max(1, std::min(grad_blocks(B), (int)grid_for(work > 0 ? work : 1, kfn)));
+  if (const char* e = getenv("PINGS_SDF_GRAD_BLOCKS")) nblocks = std::max(1, std::min(nblocks, atoi(e)));   // A/B runs
   const int PSZ = H * (IN + 2) + 1;
   GradArgs a;
   a.W1 = dec->W1; a.b1 = dec->b1; a.W2 = dec->W2;
@@ -381,7 +653,12 @@ int run(bool second, const pings_sdf_decoder* dec, const float* features, int64_
     if (second) hipLaunchKernelGGL((sdf_grad_kernel<PAD, true>), dim3(nblocks), dim3(64 * WPB), 0, st, a);    \
     else hipLaunchKernelGGL((sdf_grad_kernel<PAD, false>), dim3(nblocks), dim3(64 * WPB), 0, st, a);         \
   } while (0)
-    if (B > 0) {
+    if (B > 0 && mfma) {
+      if (need <= 12) hipLaunchKernelGGL(sdf_grad_mfma_kernel<12>, dim3(nblocks), dim3(64 * WPB), 0, st, a);
+      else if (need <= 20) hipLaunchKernelGGL(sdf_grad_mfma_kernel<20>, dim3(nblocks), dim3(64 * WPB), 0, st, a);
+      else hipLaunchKernelGGL(sdf_grad_mfma_kernel<36>, dim3(nblocks), dim3(64 * WPB), 0, st, a);
+      PINGS_LAUNCH_CHECK();
+    } else if (B > 0) {
       if (IN <= 12) PINGS_SDF_GRAD(12);
       else if (IN <= 20) PINGS_SDF_GRAD(20);
       else if (IN <= 36) PINGS_SDF_GRAD(36);

@@ -28,17 +28,6 @@ constexpr int QPW = 4;          // queries per wave step
 constexpr int NBR = 8;          // neighbour slots per query (nn_k <= 8)
 constexpr int COLS = QPW * NBR; // 32 MFMA columns
 
-__device__ inline int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-// sum over the 8-lane group of a lane (all 8 lanes get it): xor 1, xor 2 inside the quad, then the other quad through
-// row_half_mirror (lane i <-> 7 - i of the 8-lane half row, which holds the other quad's total)
-__device__ inline float group8_sum(float v) {
-  v += dpp_movf<0xb1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_movf<0x4e>(v);   // quad_perm [2,3,0,1]
-  v += dpp_movf<0x141>(v);  // row_half_mirror
-  return v;
-}
-
 template <int IN_PAD>
 struct XLayout {
   static constexpr int HALF = IN_PAD / 2;                 // k-steps: element 2t + k lives at [k][t]
@@ -205,7 +194,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_mfma_kern
       }
 #pragma unroll
       for (int rq = 0; rq < 16; ++rq) {
-        const float4 c4 = *reinterpret_cast<const float4*>(sC[mb * 32 + rowmap(rq, kh)]);
+        const float4 c4 = *reinterpret_cast<const float4*>(sC[mb * 32 + rowmap32(rq, kh)]);
         const float pre = acc[rq];
         hv = fmaf(c4.x, fmaxf(pre, 0.f), hv);
         if (GRAD) {
