@@ -253,13 +253,16 @@ def test_hip_fused_sdf_large_map_against_oracle():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
-def test_hip_fused_sdf_backward_matches_oracle_autograd(golden_dir, name):
+@pytest.mark.parametrize("kernel", ["mfma", "vector"])
+def test_hip_fused_sdf_backward_matches_oracle_autograd(golden_dir, name, kernel, monkeypatch):
     """First-order training gradients (features + decoder) of the fused kernel vs autograd through the oracle
-    (itself pinned to the reference by G1-G3)."""
+    (itself pinned to the reference by G1-G3), for both gradient kernels of `pings_sdf_backward` (csrc/sdf_bwd.hip:
+    the matrix-core one is the default where it applies, PINGS_SDF_BWD=vector forces the lane-per-hidden-unit one)."""
     from types import SimpleNamespace as NS
 
     from pings_amd import neural_points as hnp
 
+    monkeypatch.setenv("PINGS_SDF_BWD", kernel)
     st = load(golden_dir, name)
     x = T(st["x"])
     cpu = sdf_cpu.NeuralPointMap(st)
