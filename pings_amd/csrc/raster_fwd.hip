@@ -94,7 +94,7 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.ds_cnt = g.ds_head ? g.ds_head + DS_HEAD : nullptr;
   g.ds_off = c.take<uint32_t>((size_t)DS_NB + nblk + 1);
   g.ds_idx = c.take<uint32_t>(n);
-  g.stats = c.take<unsigned long long>(2 * 256);  // sharded {pairs before culling, visible Gaussians}
+  g.stats = c.take<unsigned long long>(3 * 256);  // sharded {pairs before culling, visible Gaussians, kept pairs}
   g.temp_bytes = sort_temp_bytes((int64_t)n);
   g.temp = c.take<char>(g.temp_bytes);
   g.total = c.off;
@@ -715,10 +715,16 @@ __global__ __launch_bounds__(256) void count_kept_kernel(int P, int gx, int nb,
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, 64);
   const unsigned long long vis = __ballot(me.n != 0u);
+  // the kept total once more in 64 bits: the instance offsets are a 32-bit scan, which a degenerate frame (huge
+  // footprints with the occlusion bound off) could wrap without anyone noticing
+  uint32_t kept_w = r >= 0 ? kept : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) kept_w += (uint32_t)__shfl_xor((int)kept_w, off, 64);
   if (lane == 0 && tot) {  // sharded: thousands of waves adding to one word serialise
     const int shard = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_SHARDS - 1));
-    atomicAdd(pairs_full + 2 * shard, (unsigned long long)tot);
-    atomicAdd(pairs_full + 2 * shard + 1, (unsigned long long)__popcll(vis));
+    atomicAdd(pairs_full + 3 * shard, (unsigned long long)tot);
+    atomicAdd(pairs_full + 3 * shard + 1, (unsigned long long)__popcll(vis));
+    atomicAdd(pairs_full + 3 * shard + 2, (unsigned long long)kept_w);
   }
 }
 
@@ -1895,7 +1901,7 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
   bool library_sort = false;
   if (const char* e = getenv("PINGS_DEPTH_SORT")) library_sort = e[0] == 'l';
   uint32_t total = 0;
-  static thread_local unsigned long long shards[2 * STAT_SHARDS];
+  static thread_local unsigned long long shards[3 * STAT_SHARDS];
   for (;;) {
     size_t tb = gs.temp_bytes;
     if (library_sort) {
@@ -1948,7 +1954,7 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
     }
     {
       pings::prof::Scope ps("tile_count_scan", st);
-      PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 2 * STAT_SHARDS * sizeof(unsigned long long), st));
+      PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 3 * STAT_SHARDS * sizeof(unsigned long long), st));
       hipLaunchKernelGGL(count_kept_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
                          gs.occ_bsat, gs.nvalid, gs.tiles_sorted, gs.stats);
       PINGS_LAUNCH_CHECK();
@@ -1967,8 +1973,12 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
     library_sort = true;  // a depth bucket overflowed: redo the frame with the library sort
   }
   *num_instances = (int64_t)total;
-  unsigned long long stats[2] = {0, 0};
-  for (int i = 0; i < STAT_SHARDS; ++i) { stats[0] += shards[2 * i]; stats[1] += shards[2 * i + 1]; }
+  unsigned long long stats[3] = {0, 0, 0};
+  for (int i = 0; i < STAT_SHARDS; ++i) {
+    stats[0] += shards[3 * i]; stats[1] += shards[3 * i + 1]; stats[2] += shards[3 * i + 2];
+  }
+  PINGS_ARG_CHECK(stats[2] == (unsigned long long)total && stats[2] < 0x7FFFFFFFull,
+                  "more than 2^31 - 1 (Gaussian, tile) instances in this frame");
   // Footprints of many tiles keep most lanes of a wave busy: two pixels per lane then amortise the per-record
   // work; small footprints leave lanes idle and one pixel per lane (four 8x8 waves with their own culled lists)
   // wins (measured: 52 tiles per Gaussian -> PPL 2 is 6 % faster, 5.6 tiles per Gaussian -> PPL 1 is 19 % faster).

@@ -639,3 +639,42 @@ def test_block_index_refuses_tables_it_cannot_mirror(monkeypatch):
     _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
     status = hnp._block_index(gpu).status.cpu().tolist()
     assert status[0] == 0 and status[1] == status[2] - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,H,nn_k", [(8, 32, 6), (16, 64, 8), (4, 16, 3), (32, 48, 6)])
+def test_matrix_core_sdf_kernels_other_decoder_shapes(F, H, nn_k, monkeypatch):
+    """The matrix-core forward / backward of the fused SDF query on decoder shapes the golden maps do not have (one
+    hidden block, 12- and 20-wide padded inputs, a ragged hidden width, nn_k = 8 and 3): against the vector kernels
+    (which the golden tests pin) and against the oracle."""
+    from types import SimpleNamespace as NS
+
+    from pings_amd import neural_points as hnp
+
+    st, dec = sdf_cpu.synthetic_map(6000, feat_dim=F, hidden=H, nn_k=nn_k, seed=F + H)
+    x = sdf_cpu.synthetic_queries(st, 1501)          # not a multiple of four: the last wave step is ragged
+    cpu, gpu = sdf_cpu.NeuralPointMap({**st}), _gpu_map({**st})
+    s_ref, _ = sdf_cpu.mapper_sdf(cpu, sdf_cpu.MLP.from_state({**dec}), x)
+    gw = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(1)).cuda()
+    res = {}
+    for mode in ("mfma", "vector"):
+        monkeypatch.setenv("PINGS_SDF_FWD", mode)
+        monkeypatch.setenv("PINGS_SDF_BWD", mode)
+        out = hnp.sdf_fused(gpu, _Dec({**dec}), x.cuda(), need_grad=True, need_std=True,
+                            use_only_measured_points=False)
+        feats = gpu.local_geo_features.detach().clone().requires_grad_(True)
+        gpu.local_geo_features = feats
+        P = [torch.nn.Parameter(torch.as_tensor(dec["dec." + k]).cuda().clone()) for k in
+             ("layers.0.weight", "layers.0.bias", "lout.weight", "lout.bias")]
+        d = NS(layers=[NS(weight=P[0], bias=P[1])], lout=NS(weight=P[2], bias=P[3]),
+               sdf_scale=float(_Dec({**dec}).sdf_scale), use_leaky_relu=False)
+        s, _ = hnp.sdf_train(gpu, d, x.cuda(), use_only_measured_points=False)
+        grads = torch.autograd.grad((s * gw).sum(), [feats] + P)
+        res[mode] = (out, s.detach(), grads)
+    assert rel_err(res["mfma"][1], s_ref) <= 1e-4 and rel_err(res["vector"][1], s_ref) <= 1e-4
+    for a, b in zip(res["mfma"][0], res["vector"][0]):
+        if a is None:
+            continue
+        assert torch.equal(a, b) if a.dtype == torch.int64 else rel_err(a, b) <= 2e-5
+    for a, b in zip(res["mfma"][2], res["vector"][2]):
+        assert rel_err(a, b) <= 5e-5, rel_err(a, b)
