@@ -138,17 +138,20 @@ def _max_abs_dx(npm) -> int:
 
 
 class _BlockIndex:
-    __slots__ = ("key", "blocks", "records", "status", "mask", "baked", "keep")
+    __slots__ = ("src", "versions", "scalars", "blocks", "records", "status", "mask", "baked")
 
 
-def _tensor_key(t):
-    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+def _same_tensors(held, now) -> bool:
+    return len(held) == len(now) and all(a is b for a, b in zip(held, now))
 
 
 def _block_index(npm):
     """The cell-block index of the map's search-side tensors (csrc/knn_blocks.hip), rebuilt whenever any of them
-    changes: identity, shape and torch's in-place version counter of every baked tensor, plus the generation
-    `neural_map.update` bumps after HIP kernels wrote through raw pointers."""
+    changes.  "Changes" = a different tensor OBJECT (the cache keeps the objects it was built from alive, so a new
+    tensor cannot come back at an old address: `data_ptr()` alone is not an identity — a per-frame `global2local`
+    re-created by the same op sequence has the same pointer, shape and version counter as last frame's), torch's
+    in-place version counter, or the generation `neural_map.update` bumps after HIP kernels wrote through raw
+    pointers."""
     table, pts = npm.buffer_pt_index, npm.neural_points
     N = int(pts.shape[0])
     opt = {n: getattr(npm, n, None) for n in ("point_ts_create", "travel_dist", "free_gs_mask", "valid_gs_mask",
@@ -162,16 +165,16 @@ def _block_index(npm):
     free = opt["free_gs_mask"] if opt["free_gs_mask"] is not None and opt["free_gs_mask"].shape[0] >= N else None
     valid = opt["valid_gs_mask"] if opt["valid_gs_mask"] is not None and opt["valid_gs_mask"].shape[0] >= N else None
     g2l = opt["global2local"] if opt["global2local"] is not None and opt["global2local"].shape[0] >= N else None
-    key = (_tensor_key(table), _tensor_key(pts), _tensor_key(ts), _tensor_key(td), _tensor_key(free),
-           _tensor_key(valid), _tensor_key(g2l), getattr(npm, "_pings_table_gen", 0), float(npm.resolution),
-           float(npm.max_valid_dist2), id(npm.neighbor_dx))
+    src = (table, pts, ts, td, free, valid, g2l, npm.neighbor_dx)
+    versions = tuple(-1 if t is None else t._version for t in src)
+    scalars = (getattr(npm, "_pings_table_gen", 0), float(npm.resolution), float(npm.max_valid_dist2), N)
     cache = getattr(npm, "_pings_blocks", None)
-    if cache is not None and cache.key == key:
+    if cache is not None and _same_tensors(cache.src, src) and cache.versions == versions and cache.scalars == scalars:
         return cache
     L = _L()
     dev = pts.device
     bi = _BlockIndex()
-    bi.key = key
+    bi.src, bi.versions, bi.scalars = src, versions, scalars
     entries = L.pings_knn_blocks_entries(N)
     bi.blocks = torch.empty(entries * 4, dtype=torch.int64, device=dev)
     bi.records = torch.empty(max(N, 1) * 4, dtype=torch.int64, device=dev)
@@ -192,20 +195,19 @@ def _block_index(npm):
                                   bi.blocks.data_ptr(), entries, bi.records.data_ptr(), bi.status.data_ptr(),
                                   _lib.stream_ptr(dev))
     _lib.check(st, "pings_knn_blocks_build")
-    bi.keep = None  # the build has been enqueued on the stream the tensors live on; nothing of `keep` is read later
     npm._pings_blocks = bi
     return bi
 
 
 def _compact_table(npm):
-    """Cache-resident mirror of `buffer_pt_index`, rebuilt whenever the dense tensor changes: identity, torch's
-    in-place version counter (torch-side writes), the explicit generation `neural_map.update` bumps after the HIP
-    insert kernel wrote the table through its raw pointer (which torch's counter cannot see), and the point count."""
+    """Cache-resident mirror of `buffer_pt_index`, rebuilt whenever the dense tensor changes: another tensor object
+    (the cache keeps the one it was built from alive — see `_block_index`), torch's in-place version counter
+    (torch-side writes), the explicit generation `neural_map.update` bumps after the HIP insert kernel wrote the table
+    through its raw pointer (which torch's counter cannot see), and the point count."""
     table = npm.buffer_pt_index
-    key = (table.data_ptr(), table._version, table.shape[0], getattr(npm, "_pings_table_gen", 0),
-           int(npm.neural_points.shape[0]))
+    key = (table._version, table.shape[0], getattr(npm, "_pings_table_gen", 0), int(npm.neural_points.shape[0]))
     cache = getattr(npm, "_pings_compact", None)
-    if cache is not None and cache[0] == key:
+    if cache is not None and cache[0] == key and cache[2] is table:
         return cache[1]
     L = _L()
     entries = L.pings_knn_compact_entries(int(npm.neural_points.shape[0]))
@@ -213,7 +215,7 @@ def _compact_table(npm):
     st = L.pings_knn_compact_build(_lib.ptr(table.contiguous()), int(table.shape[0]), _lib.ptr(comp), entries,
                                    _lib.stream_ptr(table.device))
     _lib.check(st, "pings_knn_compact_build")
-    npm._pings_compact = (key, comp)
+    npm._pings_compact = (key, comp, table)
     return comp
 
 

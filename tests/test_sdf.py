@@ -610,7 +610,16 @@ def test_block_index_masks_random_and_stale(monkeypatch):
     cpu.global2local[keep[:500]] = -1
     gpu.global2local[torch.from_numpy(keep[:500]).cuda()] = -1
     _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
-    assert hnp._block_index(gpu) is not first
+    second = hnp._block_index(gpu)
+    assert second is not first
+    # a per-frame tensor REPLACED by a new object of the same shape / dtype / version counter (what reset_local_map
+    # does to global2local every frame; the allocator may even hand out the old address): identity decides
+    g2 = torch.full_like(cpu.global2local, -1)
+    g2[torch.from_numpy(keep[600:])] = torch.arange(keep.shape[0] - 600)
+    cpu.global2local = g2
+    gpu.global2local = g2.cuda()
+    _assert_search_equal(_search_all_modes(cpu, gpu, x, hnp))
+    assert hnp._block_index(gpu) is not second
 
 
 @pytest.mark.gpu
