@@ -19,8 +19,8 @@ is the guide's figure.  The guide leaves other access widths uncalibrated, so pr
 of one 128-B line a wave instruction needs — streaming reads (every request a whole line): counter = 1/2 of the bytes;
 64-B tile-row pieces and 8-B random probes (half-line requests): counter = the sector bytes exactly; random 48-B records
 (1.25 lines, 1.5 sectors each): counter = 0.83 of the sector bytes; WRITE_SIZE is exact at 32-B granularity for every
-pattern tried.  `FETCH_FACTOR` below holds the factor of the kernels whose reads are NOT streaming (from the mix of
-their algorithmic reads); `hbm_bytes_calibrated` = factor x FETCH + WRITE.  Only this library's kernels are listed."""
+pattern tried.  `FETCH_FACTOR` below holds the factor of the kernels whose reads are NOT streaming;
+`hbm_bytes_calibrated` = factor x FETCH + WRITE.  Only this library's kernels are listed."""
 import collections
 import csv
 import json
@@ -30,15 +30,17 @@ import sys
 
 # kernel (short name prefix) -> (fetch factor, why).  Everything else reads wide and coalesced: factor 2.
 FETCH_FACTOR = {
-    # 149 MB of its 199 MB of reads are 64-B tile-row pieces of the pixel planes (exact), the rest 48-B records (1.2)
-    "blend_bwd_kernel": (1.07, "0.66 x tile-row planes (1.0) + 0.34 x 48-B record gathers (1.2)"),
-    "blend_bwd_scan_kernel": (1.07, "as blend_bwd_kernel"),
-    "blend_fwd_tile_kernel": (1.2, "48-B record gathers (1.2); its pixel traffic is writes"),
-    "blend_fwd_wave_kernel": (1.2, "48-B record gathers"),
-    "blend_fwd_seg_kernel": (1.2, "48-B record gathers"),
-    "sdf_forward_kernel": (1.0, "8-B hash probes and 4..32-B row gathers: one half-line request each (exact)"),
-    "qf_forward_kernel": (1.0, "as sdf_forward_kernel"),
-    "knn_search_kernel": (1.0, "as sdf_forward_kernel"),
+    # the blend kernels read 64-B tile-row pieces of the pixel planes (exact) and the per-Gaussian blend records, which
+    # are four float4 = 64 B at a 64-B stride (csrc/raster_fwd.hip: rec[4 g + 0..3]): one aligned sector each (exact,
+    # like the 8-B probes of the calibration; the 48-B pattern of pmc_calib.hip does not apply to them)
+    "blend_bwd_kernel": (1.0, "64-B tile-row pieces + 64-B aligned records: one half-line request each (exact)"),
+    "blend_bwd_scan_kernel": (1.0, "as blend_bwd_kernel"),
+    "blend_fwd_tile_kernel": (1.0, "64-B aligned records; its pixel traffic is writes"),
+    "blend_fwd_wave_kernel": (1.0, "64-B aligned records"),
+    "blend_fwd_seg_kernel": (1.0, "64-B aligned records"),
+    "sdf_forward": (1.0, "32-B block entries / records and 4..128-B row gathers: half-line requests (exact)"),
+    "qf_forward_kernel": (1.0, "as sdf_forward"),
+    "knn_search_kernel": (1.0, "as sdf_forward"),
 }
 
 
