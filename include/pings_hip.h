@@ -601,10 +601,13 @@ PINGS_API int pings_image_losses_backward(const pings_image_loss_params* p, cons
  * Replaces the Jacobian assembly of `implicit_reg` (utils/tracker.py:608-689): with J_i = [p_i x g_i, g_i] (rotation
  * first, then translation),  N = sum_i w_i J_i^T J_i  (6x6)  and  g = -sum_i w_i r_i J_i  (6).
  * points[n,3], sdf_grad[n,3], sdf_residual[n], weight[n] -> out[42] = N row-major (36) followed by g (6), fp32,
- * accumulated in fp64 with a fixed-order two-stage reduction (bitwise reproducible).  The 6x6 solve, the LM damping and
- * the exponential map stay on the host side of the ABI (a 6x6 fp64 inverse). */
+ * accumulated in fp64 with a fixed-order two-stage reduction (bitwise reproducible). */
 PINGS_API size_t pings_reg_normal_equations_scratch_bytes(void);
 PINGS_API int pings_reg_normal_equations(const float* points, const float* sdf_grad, const float* sdf_residual,
                                          const float* weight, int64_t n, void* scratch, float* out, void* stream);
+/* The rest of the step (utils/tracker.py:649-689, :774-783) from the 42 floats above: N += lm_lambda diag(N) in fp32,
+ * t = N^-1 g in fp64 (Gaussian elimination with partial pivoting), T[4,4] = [expmap(t[:3]) | t[3:]] row-major fp64;
+ * t_out[6] optional.  One tiny kernel instead of ~30 torch launches and the host sync of linalg.inv. */
+PINGS_API int pings_reg_solve(const float* normal_eq, float lm_lambda, double* T_out, double* t_out, void* stream);
 
 #endif /* PINGS_HIP_H_ */

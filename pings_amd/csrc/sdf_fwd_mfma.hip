@@ -36,7 +36,7 @@ struct XLayout {
 };
 
 template <int IN_PAD, bool GRAD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sdf_forward_mfma_kernel(
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_PAD > 36 ? 2 : 4) void sdf_forward_mfma_kernel(
     pings_knn_map m, pings_sdf_decoder dec, const float* __restrict__ features,
     const float* __restrict__ points, const float* __restrict__ orientations,
     const float* __restrict__ certainties, int after_pgo, const float* __restrict__ queries,

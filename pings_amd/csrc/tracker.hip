@@ -74,7 +74,65 @@ __global__ void reg_finish_kernel(const double* __restrict__ partial, int nblock
   }
 }
 
+// LM damping, the fp64 6x6 solve and the exponential map of one registration step (utils/tracker.py:649-689, :774-783)
+// in one single-thread kernel: the reference spends ~30 tiny torch launches and a host sync (linalg.inv checks its
+// info word) on it, 50-100 times per frame.  N is damped in fp32 like the reference's `N_mat += lambda diag(N_mat)`,
+// then everything is fp64: t = N^-1 g by Gaussian elimination with partial pivoting, R = I + S sin(a) + S^2 (1 - cos a).
+__global__ void reg_solve_kernel(const float* __restrict__ ng, float lm_lambda, double* __restrict__ T_out,
+                                 double* __restrict__ t_out) {
+  double A[6][7];
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c < 6; ++c) {
+      float v = ng[r * 6 + c];
+      if (r == c) v += lm_lambda * v;
+      A[r][c] = (double)v;
+    }
+    A[r][6] = (double)ng[36 + r];
+  }
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < 6; ++r)
+      if (fabs(A[r][k]) > fabs(A[piv][k])) piv = r;
+    if (piv != k)
+      for (int c = 0; c < 7; ++c) { const double t = A[k][c]; A[k][c] = A[piv][c]; A[piv][c] = t; }
+    const double inv = 1.0 / A[k][k];
+    for (int r = k + 1; r < 6; ++r) {
+      const double f = A[r][k] * inv;
+      for (int c = k; c < 7; ++c) A[r][c] -= f * A[k][c];
+    }
+  }
+  double t[6];
+  for (int r = 5; r >= 0; --r) {
+    double v = A[r][6];
+    for (int c = r + 1; c < 6; ++c) v -= A[r][c] * t[c];
+    t[r] = v / A[r][r];
+  }
+  const double angle = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  const double ax = t[0] / angle, ay = t[1] / angle, az = t[2] / angle;   // angle = 0 -> NaN, as the reference
+  const double S[3][3] = {{0.0, -az, ay}, {az, 0.0, -ax}, {-ay, ax, 0.0}};
+  const double sn = sin(angle), cs = 1.0 - cos(angle);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s2 = 0.0;
+      for (int k = 0; k < 3; ++k) s2 += S[r][k] * S[k][c];
+      T_out[r * 4 + c] = (r == c ? 1.0 : 0.0) + S[r][c] * sn + s2 * cs;
+    }
+  for (int r = 0; r < 3; ++r) T_out[r * 4 + 3] = t[3 + r];
+  T_out[12] = 0.0; T_out[13] = 0.0; T_out[14] = 0.0; T_out[15] = 1.0;
+  if (t_out)
+    for (int r = 0; r < 6; ++r) t_out[r] = t[r];
+}
+
 }  // namespace
+
+PINGS_API int pings_reg_solve(const float* normal_eq, float lm_lambda, double* T_out, double* t_out, void* stream) {
+  PINGS_ARG_CHECK(normal_eq && T_out, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("reg_solve", st);
+  reg_solve_kernel<<<1, 1, 0, st>>>(normal_eq, lm_lambda, T_out, t_out);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
 
 PINGS_API size_t pings_reg_normal_equations_scratch_bytes(void) { return sizeof(double) * kBlocks * kTerms; }
 

@@ -33,6 +33,8 @@ def _declare(L):
     L.pings_reg_normal_equations_scratch_bytes.argtypes = []
     L.pings_reg_normal_equations.restype = C.c_int
     L.pings_reg_normal_equations.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+    L.pings_reg_solve.restype = C.c_int
+    L.pings_reg_solve.argtypes = [vp, C.c_float, vp, vp, vp]
     L._trk_declared = True
 
 
@@ -75,14 +77,12 @@ def implicit_reg(points, sdf_grad, sdf_residual, weight, lm_lambda=0.0, require_
     """One LM step of point-to-implicit-model registration (utils/tracker.py:608-689): returns
     (T_mat[4,4] fp64, cov_mat[6,6] | None, eigenvalues[3] | None)."""
     N_mat, g_vec = normal_equations(points, sdf_grad, sdf_residual, weight)
-    N_mat = N_mat.clone()
-    if require_cov or require_eigen:
-        N_mat_raw = N_mat.clone()
-    N_mat += lm_lambda * torch.diag(torch.diag(N_mat))
-    t_vec = torch.linalg.inv(N_mat.to(dtype=torch.float64)) @ g_vec.to(dtype=torch.float64)
-    T_mat = torch.eye(4, device=points.device, dtype=torch.float64)
-    T_mat[:3, :3] = _expmap(t_vec[:3])
-    T_mat[:3, 3] = t_vec[3:]
+    N_mat_raw = N_mat
+    # damping, fp64 solve and exponential map in one kernel (`pings_reg_solve`; N_mat / g_vec are views of one buffer)
+    L = _lib.lib()
+    T_mat = torch.empty(4, 4, dtype=torch.float64, device=points.device)
+    _lib.check(L.pings_reg_solve(N_mat.data_ptr(), float(lm_lambda), T_mat.data_ptr(), None,
+                                 _lib.stream_ptr(points.device)), "pings_reg_solve")
     eigenvalues = None
     if require_eigen:
         eigenvalues = torch.linalg.eigvals(N_mat_raw[3:, 3:]).real
@@ -106,11 +106,12 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
     n = coord.shape[0]
     dev = coord.device
     iters = math.ceil(n / bs) if n else 0
-    sdf_pred = torch.zeros(n, device=dev) if query_sdf else None
-    sdf_std = torch.zeros(n, device=dev) if query_sdf else None
-    sdf_grad = torch.zeros(n, 3, device=dev) if query_sdf_grad else None
-    mc_mask = torch.zeros(n, device=dev, dtype=torch.bool) if query_mask else None
-    certainty = torch.zeros(n, device=dev) if query_certainty else None
+    single = iters == 1
+    sdf_pred = torch.zeros(n, device=dev) if query_sdf and not single else None
+    sdf_std = torch.zeros(n, device=dev) if query_sdf and not single else None
+    sdf_grad = torch.zeros(n, 3, device=dev) if query_sdf_grad and not single else None
+    mc_mask = torch.zeros(n, device=dev, dtype=torch.bool) if query_mask and not single else None
+    certainty = torch.zeros(n, device=dev) if query_certainty and not single else None
     channels = getattr(self.config, "color_channel", 3)
     color_pred = torch.zeros(n, channels, device=dev) if query_color else None
     color_grad = torch.zeros(n, channels, 3, device=dev) if query_color_grad else None
@@ -122,15 +123,25 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
             s, g, cnt, cert, std = _np.sdf_fused(npm, self.sdf_mlp, x, need_grad=bool(query_sdf_grad),
                                                  need_certainty=bool(query_certainty), query_locally=query_locally,
                                                  use_only_valid_points=True, need_std=True)
-            if query_sdf:
-                sdf_pred[head:tail] = s
-                sdf_std[head:tail] = std
-            if query_sdf_grad:
-                sdf_grad[head:tail] = g
-            if query_mask:
-                mc_mask[head:tail] = cnt >= mask_min_nn_count
-            if query_certainty:
-                certainty[head:tail] = cert
+            if iters == 1:   # the usual case (bs >= n): hand the kernel's outputs over, no zero fills, no slice copies
+                if query_sdf:
+                    sdf_pred, sdf_std = s, std
+                if query_sdf_grad:
+                    sdf_grad = g
+                if query_mask:
+                    mc_mask = cnt >= mask_min_nn_count
+                if query_certainty:
+                    certainty = cert
+            else:
+                if query_sdf:
+                    sdf_pred[head:tail] = s
+                    sdf_std[head:tail] = std
+                if query_sdf_grad:
+                    sdf_grad[head:tail] = g
+                if query_mask:
+                    mc_mask[head:tail] = cnt >= mask_min_nn_count
+                if query_certainty:
+                    certainty[head:tail] = cert
         if query_color:   # photometric term only: HIP-backed query_feature + the reference's torch tail (:322-331)
             xc = x.detach().clone().requires_grad_(bool(query_color_grad))
             _, color_feature, w_knn, _, _ = npm.query_feature(xc, accumulate_stability=False, query_locally=query_locally,
