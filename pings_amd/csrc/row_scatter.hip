@@ -1,12 +1,15 @@
 // Deterministic scatter-add of rows (see row_scatter.hpp): counting sort by destination row + one gather pass.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "row_scatter.hpp"
 
 namespace pings_rows {
 namespace {
 
 size_t au(size_t v) { return (v + 255) / 256 * 256; }
+constexpr uint32_t NO_ROW = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(256) void hist_kernel(const uint32_t* __restrict__ keys, long long n, uint32_t rows,
                                                    uint32_t* __restrict__ count) {
@@ -33,15 +36,21 @@ __global__ __launch_bounds__(256) void place_kernel(const uint32_t* __restrict__
 // O(len) loads per pair, all pairs in parallel; buckets are short (pairs per touched row).
 __global__ __launch_bounds__(256) void rank_kernel(const uint32_t* __restrict__ keys, long long n,
                                                    const uint32_t* __restrict__ offset, uint32_t rows,
-                                                   const uint32_t* __restrict__ bucket, uint32_t* __restrict__ sorted) {
+                                                   const uint32_t* __restrict__ bucket, uint32_t* __restrict__ sorted,
+                                                   uint32_t* __restrict__ first) {
   const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pos >= n || pos >= (long long)offset[rows]) return;
+  if (pos >= n) return;
+  if (pos >= (long long)offset[rows]) {   // behind the last bucket (pairs with an invalid key were not placed)
+    first[pos] = NO_ROW;
+    return;
+  }
   const uint32_t pr = bucket[pos];
   const uint32_t k = keys[pr];
   const uint32_t s = offset[k], e = offset[k + 1];
   uint32_t rank = 0;
   for (uint32_t q = s; q < e; ++q) rank += bucket[q] < pr ? 1u : 0u;
   sorted[s + rank] = pr;
+  first[s + rank] = rank == 0u ? k : NO_ROW;   // every position of the bucket is written by exactly one pair
 }
 
 // G lanes own one destination row (4 columns each); the row's pairs are summed in ascending pair id.
@@ -78,6 +87,44 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const uint32_t* __restr
   }
 }
 
+// The same sum, driven by the buckets: G lanes per sorted position, only the first position of a bucket works (the
+// table was zeroed before).  Same order of additions as gather_sum_kernel: bitwise the same rows.
+template <int G>
+__global__ __launch_bounds__(256) void gather_bucket_kernel(const uint32_t* __restrict__ offset,
+                                                            const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ first, long long n, int F,
+                                                            const float* __restrict__ src, long long ld,
+                                                            const uint32_t* __restrict__ src_row,
+                                                            const float* __restrict__ w, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long pos = t / G;
+  const int c0 = 4 * (int)(t % G);
+  if (pos >= n || c0 >= F) return;
+  const uint32_t r = first[pos];
+  if (r == NO_ROW) return;
+  const uint32_t e = offset[r + 1];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const bool c1 = c0 + 1 < F, c2 = c0 + 2 < F, c3 = c0 + 3 < F;
+  for (uint32_t q = (uint32_t)pos; q < e; ++q) {
+    const uint32_t pr = sorted[q];
+    const size_t row = (size_t)(src_row ? src_row[pr] : pr) * (size_t)ld + (size_t)c0;
+    const float ww = w ? w[pr] : 1.0f;
+    a0 = fmaf(ww, src[row], a0);
+    if (c1) a1 = fmaf(ww, src[row + 1], a1);
+    if (c2) a2 = fmaf(ww, src[row + 2], a2);
+    if (c3) a3 = fmaf(ww, src[row + 3], a3);
+  }
+  float* o = out + (size_t)r * F + c0;
+  if ((F & 3) == 0) {
+    *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);
+  } else {
+    o[0] = a0;
+    if (c1) o[1] = a1;
+    if (c2) o[2] = a2;
+    if (c3) o[3] = a3;
+  }
+}
+
 }  // namespace
 
 Plan carve(void* base, int64_t n_pairs, int64_t rows) {
@@ -90,6 +137,8 @@ Plan carve(void* base, int64_t n_pairs, int64_t rows) {
   p.offset = (uint32_t*)take((R + 2) * 4);
   p.bucket = (uint32_t*)take(n * 4);
   p.sorted = (uint32_t*)take(n * 4);
+  p.first = (uint32_t*)take(n * 4);
+  p.n = n_pairs > 0 ? n_pairs : 0;
   size_t tb = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(R + 1));
   p.temp_bytes = au(tb) + 256;
@@ -113,7 +162,7 @@ int build(const Plan& p, const uint32_t* keys, int64_t n, int64_t rows, hipStrea
                        p.count, p.bucket);
     PINGS_LAUNCH_CHECK();
     hipLaunchKernelGGL(rank_kernel, dim3(grid), dim3(256), 0, st, keys, (long long)n, p.offset, (uint32_t)rows,
-                       p.bucket, p.sorted);
+                       p.bucket, p.sorted, p.first);
     PINGS_LAUNCH_CHECK();
   }
   return PINGS_OK;
@@ -126,6 +175,29 @@ int gather_sum(const Plan& p, int64_t rows, int F, const float* src, int64_t ld,
   const int groups = (F + 3) / 4;
   int G = 1;
   while (G < groups) G <<= 1;
+  static const int force = [] {   // PINGS_ROWS_GATHER=table|buckets (A/B runs)
+    const char* e = getenv("PINGS_ROWS_GATHER");
+    return !e ? 0 : (e[0] == 't' ? 1 : 2);
+  }();
+  if ((force == 2 || (force == 0 && 4 * p.n < rows)) && p.n >= 0) {   // measured: 98k pairs / 1M rows 37 -> 30 us, 786k pairs 109 -> 112 us
+    PINGS_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * (size_t)rows * F, st));
+    if (p.n == 0) return PINGS_OK;
+    const long long bt = (long long)p.n * G;
+    const unsigned bgrid = (unsigned)((bt + 255) / 256);
+#define PINGS_GB(GG)                                                                                                 \
+  hipLaunchKernelGGL(gather_bucket_kernel<GG>, dim3(bgrid), dim3(256), 0, st, p.offset, sorted, p.first, (long long)p.n, \
+                     F, src, (long long)ld, src_row, w, out)
+    switch (G) {
+      case 1: PINGS_GB(1); break;
+      case 2: PINGS_GB(2); break;
+      case 4: PINGS_GB(4); break;
+      case 8: PINGS_GB(8); break;
+      default: PINGS_GB(16); break;
+    }
+#undef PINGS_GB
+    PINGS_LAUNCH_CHECK();
+    return PINGS_OK;
+  }
   const long long threads = (long long)rows * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
 #define PINGS_GS(GG)                                                                                              \
