@@ -297,7 +297,6 @@ def bench_sdf(dev, steps, warmup, n_points=1_000_000):
 def bench_decoder(dev, steps, warmup, n_points=125_000):
     """The five spawn decoders (pings.py:156-160; hidden 128, 8 Gaussians per neural point) forward + backward on
     n_points visible neural points through the MFMA kernel: TFLOP/s against the fp32 matrix peak (157.3 TFLOP/s)."""
-    from pings_amd.mlp import fused_mlp
     from pings_amd import _lib
 
     g = torch.Generator(device=dev).manual_seed(3)

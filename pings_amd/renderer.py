@@ -14,7 +14,7 @@ pings_amd.spawn (csrc/spawn.hip).  There is no CPU path: host tensors raise.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 

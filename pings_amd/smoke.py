@@ -3,7 +3,6 @@
 This is one of the three places allowed to import `oracle` (as the checker)."""
 from __future__ import annotations
 
-import math
 
 import torch
 

@@ -9,7 +9,7 @@ needs, reuse the HIP-backed `query_feature` with the reference's own torch tail.
 
 `implicit_reg` — drop-in for the module-level function (utils/tracker.py:608-689): the 6x6 normal equations come from
 `pings_reg_normal_equations` (one pass, fp64 accumulation, fixed-order reduction); LM damping, the fp64 6x6 solve and
-the exponential map follow the reference line by line.
+the exponential map run in `pings_reg_solve` (one single-thread kernel, the reference's formulas).
 
 `install(tracker_module)` rebinds both.  Host tensors raise: there is no CPU path (oracle/tracker_cpu.py is the
 CPU restatement used by the tests).
@@ -54,23 +54,6 @@ def normal_equations(points, sdf_grad, sdf_residual, weight):
     _lib.check(L.pings_reg_normal_equations(_lib.ptr(p), _lib.ptr(g), _lib.ptr(r), _lib.ptr(w), n, _lib.ptr(scratch),
                                             _lib.ptr(out), _lib.stream_ptr(dev)), "pings_reg_normal_equations")
     return out[:36].view(6, 6), out[36:]
-
-
-def _skew(v):
-    S = torch.zeros(3, 3, device=v.device, dtype=v.dtype)
-    S[0, 1], S[0, 2] = -v[2], v[1]
-    S[1, 0], S[1, 2] = v[2], -v[0]
-    S[2, 0], S[2, 1] = -v[1], v[0]
-    return S
-
-
-def _expmap(axis_angle):
-    """utils/tracker.py:774-783."""
-    angle = axis_angle.norm()
-    axis = axis_angle / angle
-    eye = torch.eye(3, device=axis_angle.device, dtype=axis_angle.dtype)
-    S = _skew(axis)
-    return eye + S * torch.sin(angle) + (S @ S) * (1.0 - torch.cos(angle))
 
 
 def implicit_reg(points, sdf_grad, sdf_residual, weight, lm_lambda=0.0, require_cov=False, require_eigen=False):
