@@ -374,6 +374,116 @@ __device__ inline int select_topk(const pings_knn_map& m, Cand& c, int lane, lon
   return count;
 }
 
+// ---- two queries at once ---------------------------------------------------------------------------------------------
+// The per-query search is a chain of dependent loads (block entry -> record) followed by the selection rounds; a wave
+// that handles several queries per step (sdf_fwd_mfma.hip) gathers the candidates of TWO of them together, so that the
+// block-entry loads of both and then the record loads of both are in flight at once: half the exposed round trips.
+struct Cand32 {
+  unsigned key[2];
+  int cidx[2], gidx[2];
+  float px[2], py[2], pz[2];
+};
+
+template <int NQ>
+__device__ inline void candidates_blocks_multi(const pings_knn_map& m, const LaneCtx& lc, const float (&q)[NQ][3],
+                                               Cand32 (&c)[NQ]) {
+  const uint4* tab = reinterpret_cast<const uint4*>(m.blocks);
+  const uint4* recs = reinterpret_cast<const uint4*>(m.block_records);
+  const float lim = (float)(4 * BLOCK_COORD_LIMIT - 256);
+  bool q_in[NQ];
+  unsigned long long key[NQ][2];
+  unsigned slot[NQ][2], bit[NQ][2];
+  uint4 e[NQ][2];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) {
+    const float fx = floorf(q[u][0] / m.resolution), fy = floorf(q[u][1] / m.resolution),
+                fz = floorf(q[u][2] / m.resolution);
+    q_in[u] = fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim;
+    const int gx = q_in[u] ? (int)fx : 0, gy = q_in[u] ? (int)fy : 0, gz = q_in[u] ? (int)fz : 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int cx = gx + lc.dx[r][0], cy = gy + lc.dx[r][1], cz = gz + lc.dx[r][2];
+      key[u][r] = block_key(cx >> 2, cy >> 2, cz >> 2);
+      bit[u][r] = cell_bit(cx, cy, cz);
+      slot[u][r] = block_slot(key[u][r], m.block_mask);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) e[u][r] = tab[2 * (size_t)slot[u][r]];
+  unsigned base[NQ][2];
+  bool found[NQ][2];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned long long k = ((unsigned long long)e[u][r].y << 32) | e[u][r].x;
+      while (k != key[u][r] && k != 0ull) {
+        slot[u][r] = (slot[u][r] + 1u) & m.block_mask;
+        e[u][r] = tab[2 * (size_t)slot[u][r]];
+        k = ((unsigned long long)e[u][r].y << 32) | e[u][r].x;
+      }
+      const unsigned long long mask = ((unsigned long long)e[u][r].w << 32) | e[u][r].z;
+      found[u][r] = q_in[u] && lc.has[r] && k == key[u][r] && ((mask >> bit[u][r]) & 1ull);
+      const unsigned before = (unsigned)__popcll(mask & ((1ull << bit[u][r]) - 1ull));
+      base[u][r] = found[u][r] ? tab[2 * (size_t)slot[u][r] + 1].x + before : 0u;
+    }
+  uint4 ra[NQ][2], rb[NQ][2];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      ra[u][r] = recs[2 * (size_t)base[u][r]];
+      rb[u][r] = recs[2 * (size_t)base[u][r] + 1];
+    }
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float px = __uint_as_float(ra[u][r].x), py = __uint_as_float(ra[u][r].y), pz = __uint_as_float(ra[u][r].z);
+      const int gi = (int)ra[u][r].w, li = m.global2local ? (int)rb[u][r].x : gi;
+      const float td = __uint_as_float(rb[u][r].y);
+      const unsigned fl = rb[u][r].z;
+      const float sx = px - q[u][0], sy = py - q[u][1], sz = pz - q[u][2];
+      const float dd = (sx * sx + sy * sy) + sz * sz;
+      bool ok = found[u][r];
+      if (m.time_filtering) ok = ok && (fabsf(lc.cur_td - td) < m.diff_travel_dist_local);
+      ok = ok && !(dd > m.max_valid_dist2);
+      ok = ok && !(m.use_free_mask && (fl & 1u));
+      ok = ok && !(m.use_valid_mask && !(fl & 2u));
+      ok = ok && (li >= 0);
+      c[u].px[r] = px; c[u].py[r] = py; c[u].pz[r] = pz;
+      c[u].cidx[r] = ok ? li : -1;
+      c[u].gidx[r] = ok ? gi : -1;
+      c[u].key[r] = lc.has[r] ? __float_as_uint(ok ? dd : INVALID_D2) : 0xFFFFFFFFu;
+    }
+}
+
+__device__ inline int select_topk32(const pings_knn_map& m, Cand32& c, int lane, long long* sIdx, float* sD2,
+                                    long long* sGIdx, float* sPos) {
+  const int count = __popcll(__ballot(c.cidx[0] >= 0)) + __popcll(__ballot(c.cidx[1] >= 0));
+  for (int i = 0; i < m.nn_k; ++i) {
+    const unsigned best = wave_min_u32_all(min(c.key[0], c.key[1]));
+    const unsigned long long b0 = __ballot(c.key[0] == best);
+    const unsigned long long b1 = __ballot(c.key[1] == best);
+    const int which = b0 != 0ull ? 0 : 1;
+    const int owner = __ffsll((long long)(which ? b1 : b0)) - 1;
+    if (lane == owner) {
+      sIdx[i] = (long long)(which ? c.cidx[1] : c.cidx[0]);
+      sGIdx[i] = (long long)(which ? c.gidx[1] : c.gidx[0]);
+      sD2[i] = __uint_as_float(best);
+      if (sPos) {
+        sPos[3 * i] = which ? c.px[1] : c.px[0];
+        sPos[3 * i + 1] = which ? c.py[1] : c.py[0];
+        sPos[3 * i + 2] = which ? c.pz[1] : c.pz[0];
+      }
+      if (which) c.key[1] = 0xFFFFFFFFu; else c.key[0] = 0xFFFFFFFFu;
+    }
+  }
+  return count;
+}
+
 // Search + selection for one query (whole wave), nothing prefetched.
 __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
                                     int lane, long long* sIdx, float* sD2, long long* sGIdx, float* sPos = nullptr) {

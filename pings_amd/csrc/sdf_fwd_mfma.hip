@@ -27,6 +27,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int QPW = 4;          // queries per wave step
 constexpr int NBR = 8;          // neighbour slots per query (nn_k <= 8)
 constexpr int COLS = QPW * NBR; // 32 MFMA columns
+#ifndef PINGS_SDF_SEARCH_GROUP
+#define PINGS_SDF_SEARCH_GROUP 2
+#endif
+constexpr int SQ = PINGS_SDF_SEARCH_GROUP;   // queries whose candidate loads are issued together (1, 2 or 4): measured
+                                            // at B = 131,072 0.201 / 0.189 / 0.205 ms (4 spills 38 registers); the same pairing
+                                            // in qf_forward_kernel, which writes 140-B rows per neighbour, lost (0.233 -> 0.288)
 
 template <int IN_PAD>
 struct XLayout {
@@ -99,18 +105,38 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_PAD > 36 ? 2 : 4) void sdf
   const long long ngroups = (B + QPW - 1) / QPW;
   const long long nwaves = (long long)gridDim.x * WAVES_PER_BLOCK;
   for (long long g = (long long)blockIdx.x * WAVES_PER_BLOCK + wave; g < ngroups; g += nwaves) {
-    // ---- the four searches
+    // ---- the four searches, SQ at a time (knn_common.hpp: candidates_blocks_multi)
 #pragma unroll 1
-    for (int j = 0; j < QPW; ++j) {
-      const long long q = g * QPW + j;
-      if (q < B) {
-        const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
-        const int count = knn_one_query(m, lc, qx, qy, qz, lane, sIdx[wave] + NBR * j, sD2[wave] + NBR * j,
-                                        sGIdx[wave] + NBR * j, sPos[wave] + 3 * NBR * j);
-        if (lane == 0) sCnt[wave][j] = count;
-      } else if (lane < NBR) {
-        sIdx[wave][NBR * j + lane] = -1;
-        sD2[wave][NBR * j + lane] = INVALID_D2;
+    for (int j = 0; j < QPW; j += SQ) {
+      const long long q0 = g * QPW + j;
+      if (lc.use_blocks && q0 + SQ - 1 < B) {
+        float qq[SQ][3];
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) {
+          qq[u][0] = queries[3 * (q0 + u)]; qq[u][1] = queries[3 * (q0 + u) + 1]; qq[u][2] = queries[3 * (q0 + u) + 2];
+        }
+        Cand32 c[SQ];
+        candidates_blocks_multi<SQ>(m, lc, qq, c);
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) {
+          const int count = select_topk32(m, c[u], lane, sIdx[wave] + NBR * (j + u), sD2[wave] + NBR * (j + u),
+                                          sGIdx[wave] + NBR * (j + u), sPos[wave] + 3 * NBR * (j + u));
+          if (lane == 0) sCnt[wave][j + u] = count;
+        }
+        continue;
+      }
+#pragma unroll 1
+      for (int u = 0; u < SQ; ++u) {
+        const long long q = q0 + u;
+        if (q < B) {
+          const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+          const int count = knn_one_query(m, lc, qx, qy, qz, lane, sIdx[wave] + NBR * (j + u), sD2[wave] + NBR * (j + u),
+                                          sGIdx[wave] + NBR * (j + u), sPos[wave] + 3 * NBR * (j + u));
+          if (lane == 0) sCnt[wave][j + u] = count;
+        } else if (lane < NBR) {
+          sIdx[wave][NBR * (j + u) + lane] = -1;
+          sD2[wave][NBR * (j + u) + lane] = INVALID_D2;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
