@@ -687,3 +687,11 @@ def test_matrix_core_sdf_kernels_other_decoder_shapes(F, H, nn_k, monkeypatch):
         assert torch.equal(a, b) if a.dtype == torch.int64 else rel_err(a, b) <= 2e-5
     for a, b in zip(res["mfma"][2], res["vector"][2]):
         assert rel_err(a, b) <= 5e-5, rel_err(a, b)
+    # tiny batches: every fill level of the last four-query wave step
+    ref_s = res["vector"][1]
+    monkeypatch.setenv("PINGS_SDF_FWD", "mfma")
+    monkeypatch.setenv("PINGS_SDF_BWD", "mfma")
+    for nb in (1, 2, 3, 5):
+        s_small, _, cnt_small, _ = hnp.sdf_fused(gpu, _Dec({**dec}), x[:nb].cuda(), use_only_measured_points=False)
+        assert torch.equal(s_small, res["mfma"][0][0][:nb]) and rel_err(s_small, ref_s[:nb]) <= 2e-5
+        assert torch.equal(cnt_small, res["mfma"][0][2][:nb])
