@@ -44,62 +44,6 @@ constexpr int BATCH = 64;
 constexpr uint32_t DEAD_ROW = 0xFFFFFFFFu;
 constexpr int CH = 64;  // rows per first-level chunk of the per-Gaussian sum
 
-template <int CTRL>
-__device__ inline float dpp_mov(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-
-// 4-way lane-dependent select t[(m + K) & 3], m = 2*m1 + m0 (3 v_cndmask).
-template <int K>
-__device__ inline float sel4(const float (&t)[4], bool m0, bool m1) {
-  const float lo = m0 ? t[(1 + K) & 3] : t[K & 3];
-  const float hi = m0 ? t[(3 + K) & 3] : t[(2 + K) & 3];
-  return m1 ? hi : lo;
-}
-
-// Sums v[0..15] over the 64 lanes with a transposed reduce-scatter: two quad_perm exchange
-// steps (16 -> 8 -> 4 values per lane), one rotate step inside each 16-lane row (4 -> 1) and
-// two cross-row adds.  Afterwards lane l of EVERY row holds the wave total of slot
-//   8*(l&1) + 4*((l>>1)&1) + ((l>>2)&3).
-__device__ inline float wave_reduce16(const float (&v)[16], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float u[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float send = b0 ? v[k] : v[k + 8];
-    const float keep = b0 ? v[k + 8] : v[k];
-    u[k] = keep + dpp_mov<0xb1>(send);  // quad_perm [1,0,3,2]
-  }
-  float t[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float send = b1 ? u[k] : u[k + 4];
-    const float keep = b1 ? u[k + 4] : u[k];
-    t[k] = keep + dpp_mov<0x4e>(send);  // quad_perm [2,3,0,1]
-  }
-  // lanes {c, c+4, c+8, c+12} of a row share the slot base; lane c+4m ends with slot base+m.
-  // row_ror:4k delivers the value of lane (l - 4k) mod 16, whose group index is m-k, so a
-  // sender with group index m' offers t[(m'+k)&3].
-  const bool m0 = lane & 4, m1 = lane & 8;
-  float r = sel4<0>(t, m0, m1);
-  r += dpp_mov<0x124>(sel4<1>(t, m0, m1));  // row_ror:4
-  r += dpp_mov<0x128>(sel4<2>(t, m0, m1));  // row_ror:8
-  r += dpp_mov<0x12c>(sel4<3>(t, m0, m1));  // row_ror:12
-  // cross-row adds r[l] + r[l ^ 16], then + the same of l ^ 32, on the vector ALU: gfx950's v_permlane16_swap /
-  // v_permlane32_swap exchange rows / halves between two registers, no LDS round trip (a ds_bpermute costs ~64 cycles
-  // of latency, twice per record here).  Inline asm: this hipcc maps both results of the builtin to one register.
-  {
-    float a = r, b = r;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    r = a + b;
-    a = r; b = r;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    r = a + b;
-  }
-  return r;
-}
-
 // PPL = pixels per lane (same lane -> pixel map as blend_fwd_kernel): the 16 gradient terms of a
 // lane's PPL pixels are summed in registers before the wave reduction, which is the expensive part.
 template <int MODE, int PPL>

@@ -1631,67 +1631,84 @@ __global__ __launch_bounds__(64) void blend_fwd_tile_kernel(
     if (MODE == MODE_3DGS) sCnt[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
 
-    for (int j = 0; j < n; ++j) {
-      const float4 a = sA[j], b = sB[j], c = sC[j];
-      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (MODE == MODE_SURFEL) nn = sD[j];
-      float dxv[2], p0v[2], pxyv[2];
+    // Records in groups of 16: every record's weight sum over the tile's pixels (and, 3DGS, its count of pixels it is
+    // the dominant contributor of) stays in a register until the group is done, then ONE transposed reduce-scatter
+    // (raster_common.hpp: wave_reduce16, ~55 vector ops for 16 sums) replaces sixteen 7-step DPP reductions and their
+    // dependent chains.  The unrolled group keeps the register indices static.
+    bool stop_all = false;
+    for (int j0 = 0; j0 < n && !stop_all; j0 += 16) {
+      float ws[16], wc[16];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        dxv[h] = a.x - pixf_x[h];
-        p0v[h] = -0.5f * (b.x * dxv[h] * dxv[h]);
-        pxyv[h] = b.y * dxv[h];
-      }
-      float alpha[PPL], test_T[PPL];
-      bool contrib[PPL];
-      bool any_c = false;
+      for (int jj = 0; jj < 16; ++jj) { ws[jj] = 0.f; wc[jj] = 0.f; }
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const float dy = a.y - pixf_y[k >> 1];
-        const float power = (p0v[k & 1] - 0.5f * (b.z * dy * dy)) - pxyv[k & 1] * dy;
-        alpha[k] = fminf(ALPHA_MAX, a.z * __expf(power));
-        const bool valid = !done[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
-        test_T[k] = T[k] * (1.0f - alpha[k]);
-        const bool stop = valid && (test_T[k] < T_EPS);
-        contrib[k] = valid && !stop;
-        done[k] = done[k] || stop;
-        any_c = any_c || contrib[k];
-      }
-      if (__any(any_c)) {
-        float wsum = 0.f;
-        uint32_t touched = 0;
-        const uint32_t e1 = (uint32_t)(sE[j] + 1);
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        if (j >= n || stop_all) continue;   // wave-uniform
+        const float4 a = sA[j], b = sB[j], c = sC[j];
+        float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == MODE_SURFEL) nn = sD[j];
+        float dxv[2], p0v[2], pxyv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          dxv[h] = a.x - pixf_x[h];
+          p0v[h] = -0.5f * (b.x * dxv[h] * dxv[h]);
+          pxyv[h] = b.y * dxv[h];
+        }
+        float alpha[PPL], test_T[PPL];
+        bool contrib[PPL];
+        bool any_c = false;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
-          const float w = contrib[k] ? alpha[k] * T[k] : 0.f;
-          C0[k] = fmaf(c.x, w, C0[k]);
-          C1[k] = fmaf(c.y, w, C1[k]);
-          C2[k] = fmaf(c.z, w, C2[k]);
-          if (MODE == MODE_SURFEL) {
-            const float den = (nn.x * rx[k & 1] + nn.y * ry[k >> 1]) + nn.z;
-            float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
-            d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
-            N0[k] = fmaf(nn.x, w, N0[k]);
-            N1[k] = fmaf(nn.y, w, N1[k]);
-            N2[k] = fmaf(nn.z, w, N2[k]);
-            D[k] = fmaf(d, w, D[k]);
-          } else {
-            D[k] = fmaf(a.w, w, D[k]);
-            touched += (contrib[k] && test_T[k] > 0.5f) ? 1u : 0u;
+          const float dy = a.y - pixf_y[k >> 1];
+          const float power = (p0v[k & 1] - 0.5f * (b.z * dy * dy)) - pxyv[k & 1] * dy;
+          alpha[k] = fminf(ALPHA_MAX, a.z * __expf(power));
+          const bool valid = !done[k] && (power <= 0.0f) && (alpha[k] >= ALPHA_MIN);
+          test_T[k] = T[k] * (1.0f - alpha[k]);
+          const bool stop = valid && (test_T[k] < T_EPS);
+          contrib[k] = valid && !stop;
+          done[k] = done[k] || stop;
+          any_c = any_c || contrib[k];
+        }
+        if (__any(any_c)) {
+          float wsum = 0.f;
+          uint32_t touched = 0;
+          const uint32_t e1 = (uint32_t)(sE[j] + 1);
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            const float w = contrib[k] ? alpha[k] * T[k] : 0.f;
+            C0[k] = fmaf(c.x, w, C0[k]);
+            C1[k] = fmaf(c.y, w, C1[k]);
+            C2[k] = fmaf(c.z, w, C2[k]);
+            if (MODE == MODE_SURFEL) {
+              const float den = (nn.x * rx[k & 1] + nn.y * ry[k >> 1]) + nn.z;
+              float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+              d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+              N0[k] = fmaf(nn.x, w, N0[k]);
+              N1[k] = fmaf(nn.y, w, N1[k]);
+              N2[k] = fmaf(nn.z, w, N2[k]);
+              D[k] = fmaf(d, w, D[k]);
+            } else {
+              D[k] = fmaf(a.w, w, D[k]);
+              touched += (contrib[k] && test_T[k] > 0.5f) ? 1u : 0u;
+            }
+            T[k] = contrib[k] ? test_T[k] : T[k];
+            last[k] = contrib[k] ? e1 : last[k];
+            wsum += w;
           }
-          T[k] = contrib[k] ? test_T[k] : T[k];
-          last[k] = contrib[k] ? e1 : last[k];
-          wsum += w;
+          ws[jj] = wsum;
+          if (MODE == MODE_3DGS) wc[jj] = (float)touched;   // <= 4 per lane, <= 256 per record: exact in fp32
         }
-        const float s = wave_reduce_sum_dpp(wsum);
-        if (lane == 63) sW[j] = s;
-        if (MODE == MODE_3DGS) {
-          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
-          if (lane == 63) sCnt[j] = cn;
-        }
+        all_done_lane = (done[0] && done[1]) && (done[2] && done[3]);
+        stop_all = __all(all_done_lane);
       }
-      all_done_lane = (done[0] && done[1]) && (done[2] && done[3]);
-      if (__all(all_done_lane)) break;
+      // lane l of every 16-lane row ends with the total of slot 8*(l&1) + 4*((l>>1)&1) + ((l>>2)&3)
+      const int slot16 = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + ((lane >> 2) & 3);
+      const float tw = wave_reduce16(ws, lane);
+      if (lane < 16 && j0 + slot16 < n) sW[j0 + slot16] = tw;
+      if (MODE == MODE_3DGS) {
+        const float tc = wave_reduce16(wc, lane);
+        if (lane < 16 && j0 + slot16 < n) sCnt[j0 + slot16] = (uint32_t)tc;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {
