@@ -1177,49 +1177,60 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
     if (MODE == MODE_3DGS) sCnt[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
 
-    for (int j = 0; j < n; ++j) {
-      const float4 a = sA[j], b = sB[j], c = sC[j];
-      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (MODE == MODE_SURFEL) nn = sD[j];
-      const float dx = a.x - pixf_x;
-      const float p0 = -0.5f * (b.x * dx * dx);
-      const float pxy = b.y * dx;
-      const float dy = a.y - pixf_y;
-      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
-      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
-      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      const float test_T = T * (1.0f - alpha);
-      const bool stop = valid && (test_T < T_EPS);
-      const bool contrib = valid && !stop;
-      done = done || stop;
-      if (__any(contrib)) {
-        const float w = contrib ? alpha * T : 0.f;
-        C0 = fmaf(c.x, w, C0);
-        C1 = fmaf(c.y, w, C1);
-        C2 = fmaf(c.z, w, C2);
-        uint32_t touched = 0;
-        if (MODE == MODE_SURFEL) {
-          const float den = (nn.x * rx + nn.y * ry) + nn.z;
-          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
-          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
-          N0 = fmaf(nn.x, w, N0);
-          N1 = fmaf(nn.y, w, N1);
-          N2 = fmaf(nn.z, w, N2);
-          D = fmaf(d, w, D);
-        } else {
-          D = fmaf(a.w, w, D);
-          touched = (contrib && test_T > 0.5f) ? 1u : 0u;
+    // records in groups of 16, their weight sums reduced together (see blend_fwd_tile_kernel)
+    bool stop_all = false;
+    for (int j0 = 0; j0 < n && !stop_all; j0 += 16) {
+      float ws[16], wc[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) { ws[jj] = 0.f; wc[jj] = 0.f; }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = j0 + jj;
+        if (j >= n || stop_all) continue;   // wave-uniform
+        const float4 a = sA[j], b = sB[j], c = sC[j];
+        float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == MODE_SURFEL) nn = sD[j];
+        const float dx = a.x - pixf_x;
+        const float p0 = -0.5f * (b.x * dx * dx);
+        const float pxy = b.y * dx;
+        const float dy = a.y - pixf_y;
+        const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+        const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+        const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+        const float test_T = T * (1.0f - alpha);
+        const bool stop = valid && (test_T < T_EPS);
+        const bool contrib = valid && !stop;
+        done = done || stop;
+        if (__any(contrib)) {
+          const float w = contrib ? alpha * T : 0.f;
+          C0 = fmaf(c.x, w, C0);
+          C1 = fmaf(c.y, w, C1);
+          C2 = fmaf(c.z, w, C2);
+          if (MODE == MODE_SURFEL) {
+            const float den = (nn.x * rx + nn.y * ry) + nn.z;
+            float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+            d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+            N0 = fmaf(nn.x, w, N0);
+            N1 = fmaf(nn.y, w, N1);
+            N2 = fmaf(nn.z, w, N2);
+            D = fmaf(d, w, D);
+          } else {
+            D = fmaf(a.w, w, D);
+            wc[jj] = (contrib && test_T > 0.5f) ? 1.f : 0.f;
+          }
+          T = contrib ? test_T : T;
+          last = contrib ? (uint32_t)(sE[j] + 1) : last;
+          ws[jj] = w;
         }
-        T = contrib ? test_T : T;
-        last = contrib ? (uint32_t)(sE[j] + 1) : last;
-        const float s = wave_reduce_sum_dpp(w);
-        if (lane == 63) sW[j] = s;
-        if (MODE == MODE_3DGS) {
-          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
-          if (lane == 63) sCnt[j] = cn;
-        }
+        stop_all = __all(done);
       }
-      if (__all(done)) break;
+      const int slot16 = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + ((lane >> 2) & 3);
+      const float tw = wave_reduce16(ws, lane);
+      if (lane < 16 && j0 + slot16 < n) sW[j0 + slot16] = tw;
+      if (MODE == MODE_3DGS) {
+        const float tc = wave_reduce16(wc, lane);
+        if (lane < 16 && j0 + slot16 < n) sCnt[j0 + slot16] = (uint32_t)tc;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {
@@ -1412,55 +1423,75 @@ __global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
     }
     __builtin_amdgcn_wave_barrier();
 
-    for (int j = 0; j < n; ++j) {
-      const float4 a = sA[j], b = sB[j];
-      const float dx = a.x - pixf_x;
-      const float p0 = -0.5f * (b.x * dx * dx);
-      const float pxy = b.y * dx;
-      const float dy = a.y - pixf_y;
-      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
-      const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
-      if (PASS == 0) {
+    if (PASS == 0) {
+      for (int j = 0; j < n; ++j) {
+        const float4 a = sA[j], b = sB[j];
+        const float dx = a.x - pixf_x;
+        const float p0 = -0.5f * (b.x * dx * dx);
+        const float pxy = b.y * dx;
+        const float dy = a.y - pixf_y;
+        const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+        const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
         const bool valid = inside && (power <= 0.0f) && (alpha >= ALPHA_MIN);
         T = valid ? T * (1.0f - alpha) : T;
-        continue;
       }
-      const float4 c = sC[j];
-      float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (MODE == MODE_SURFEL) nn = sD[j];
-      const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      const float test_T = T * (1.0f - alpha);
-      const bool stop = valid && (test_T < T_EPS);
-      const bool contrib = valid && !stop;
-      done = done || stop;
-      if (__any(contrib)) {
-        const float w = contrib ? alpha * T : 0.f;
-        C0 = fmaf(c.x, w, C0);
-        C1 = fmaf(c.y, w, C1);
-        C2 = fmaf(c.z, w, C2);
-        uint32_t touched = 0;
-        if (MODE == MODE_SURFEL) {
-          const float den = (nn.x * rx + nn.y * ry) + nn.z;
-          float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
-          d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
-          N0 = fmaf(nn.x, w, N0);
-          N1 = fmaf(nn.y, w, N1);
-          N2 = fmaf(nn.z, w, N2);
-          D = fmaf(d, w, D);
-        } else {
-          D = fmaf(a.w, w, D);
-          touched = (contrib && test_T > 0.5f) ? 1u : 0u;
+    } else {
+      // records in groups of 16, their weight sums reduced together (see blend_fwd_tile_kernel)
+      bool stop_all = false;
+      for (int j0 = 0; j0 < n && !stop_all; j0 += 16) {
+        float ws[16], wc[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) { ws[jj] = 0.f; wc[jj] = 0.f; }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int j = j0 + jj;
+          if (j >= n || stop_all) continue;   // wave-uniform
+          const float4 a = sA[j], b = sB[j];
+          const float dx = a.x - pixf_x;
+          const float p0 = -0.5f * (b.x * dx * dx);
+          const float pxy = b.y * dx;
+          const float dy = a.y - pixf_y;
+          const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;
+          const float alpha = fminf(ALPHA_MAX, a.z * __expf(power));
+          const float4 c = sC[j];
+          float4 nn = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MODE == MODE_SURFEL) nn = sD[j];
+          const bool valid = !done && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+          const float test_T = T * (1.0f - alpha);
+          const bool stop = valid && (test_T < T_EPS);
+          const bool contrib = valid && !stop;
+          done = done || stop;
+          if (__any(contrib)) {
+            const float w = contrib ? alpha * T : 0.f;
+            C0 = fmaf(c.x, w, C0);
+            C1 = fmaf(c.y, w, C1);
+            C2 = fmaf(c.z, w, C2);
+            if (MODE == MODE_SURFEL) {
+              const float den = (nn.x * rx + nn.y * ry) + nn.z;
+              float d = den < -DEN_EPS ? c.w * __builtin_amdgcn_rcpf(den) : a.w;
+              d = fminf(fmaxf(d, a.w - b.w), a.w + b.w);
+              N0 = fmaf(nn.x, w, N0);
+              N1 = fmaf(nn.y, w, N1);
+              N2 = fmaf(nn.z, w, N2);
+              D = fmaf(d, w, D);
+            } else {
+              D = fmaf(a.w, w, D);
+              wc[jj] = (contrib && test_T > 0.5f) ? 1.f : 0.f;
+            }
+            T = contrib ? test_T : T;
+            last = contrib ? (uint32_t)(sE[j] + 1) : last;
+            ws[jj] = w;
+          }
+          stop_all = __all(done);
         }
-        T = contrib ? test_T : T;
-        last = contrib ? (uint32_t)(sE[j] + 1) : last;
-        const float s = wave_reduce_sum_dpp(w);
-        if (lane == 63) sW[j] = s;
+        const int slot16 = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + ((lane >> 2) & 3);
+        const float tw = wave_reduce16(ws, lane);
+        if (lane < 16 && j0 + slot16 < n) sW[j0 + slot16] = tw;
         if (MODE == MODE_3DGS) {
-          const uint32_t cn = wave_reduce_sum_u32_dpp(touched);
-          if (lane == 63) sCnt[j] = cn;
+          const float tc = wave_reduce16(wc, lane);
+          if (lane < 16 && j0 + slot16 < n) sCnt[j0 + slot16] = (uint32_t)tc;
         }
       }
-      if (__all(done)) break;
     }
     __builtin_amdgcn_wave_barrier();
     if (PASS == 1 && lane < n) {
