@@ -198,6 +198,7 @@ __global__ __launch_bounds__(BLOCK / PPL, PPL == 4 ? 3 : 4) void blend_bwd_kerne
     int jnext = cnt > 1 ? (int)sList[wave][cnt - 2] : 0;
     float4 a = sA[jcur], bq = sB[jcur], c = sC[jcur], nn = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == MODE_SURFEL) nn = sD[jcur];
+    // (unrolling this loop by two so that a record's reduction overlaps the next record's pixel math: no change, 0.349 ms)
     for (int jj = cnt - 1; jj >= 0; --jj) {
       const int j = jcur;
       const int jn = jnext;
