@@ -520,6 +520,8 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
       const float raw = a.z * G;
       const float alpha = fminf(ALPHA_MAX, raw);
       const bool valid = (e < last_p) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+      if (!__any(valid)) continue;                          // no record of the chunk reaches this pixel: its state
+                                                            // (T / 1, R + 0) and every gradient sum stay as they are
       const float av = valid ? alpha : 0.f;
       const float P_in = wave_incl_scan_mul(1.0f - av);     // product of (1 - alpha) over this and the records behind
       const float P_ex = wave_shr1(P_in, 1.0f);
