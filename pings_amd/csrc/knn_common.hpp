@@ -484,6 +484,46 @@ __device__ inline int select_topk32(const pings_knn_map& m, Cand32& c, int lane,
   return count;
 }
 
+// The selections of two candidate sets in one loop: the two chains of wave minima / ballots are independent, so the
+// scheduler interleaves them (a round is ~10 dependent cross-lane steps).
+__device__ inline void select_topk32_pair(const pings_knn_map& m, Cand32 (&c)[2], int lane, long long* sIdx0,
+                                          float* sD20, long long* sGIdx0, float* sPos0, long long* sIdx1, float* sD21,
+                                          long long* sGIdx1, float* sPos1, int& count0, int& count1) {
+  count0 = __popcll(__ballot(c[0].cidx[0] >= 0)) + __popcll(__ballot(c[0].cidx[1] >= 0));
+  count1 = __popcll(__ballot(c[1].cidx[0] >= 0)) + __popcll(__ballot(c[1].cidx[1] >= 0));
+  for (int i = 0; i < m.nn_k; ++i) {
+    const unsigned bestA = wave_min_u32_all(min(c[0].key[0], c[0].key[1]));
+    const unsigned bestB = wave_min_u32_all(min(c[1].key[0], c[1].key[1]));
+    const unsigned long long a0 = __ballot(c[0].key[0] == bestA), a1 = __ballot(c[0].key[1] == bestA);
+    const unsigned long long b0 = __ballot(c[1].key[0] == bestB), b1 = __ballot(c[1].key[1] == bestB);
+    const int whichA = a0 != 0ull ? 0 : 1, whichB = b0 != 0ull ? 0 : 1;
+    const int ownerA = __ffsll((long long)(whichA ? a1 : a0)) - 1;
+    const int ownerB = __ffsll((long long)(whichB ? b1 : b0)) - 1;
+    if (lane == ownerA) {
+      sIdx0[i] = (long long)(whichA ? c[0].cidx[1] : c[0].cidx[0]);
+      sGIdx0[i] = (long long)(whichA ? c[0].gidx[1] : c[0].gidx[0]);
+      sD20[i] = __uint_as_float(bestA);
+      if (sPos0) {
+        sPos0[3 * i] = whichA ? c[0].px[1] : c[0].px[0];
+        sPos0[3 * i + 1] = whichA ? c[0].py[1] : c[0].py[0];
+        sPos0[3 * i + 2] = whichA ? c[0].pz[1] : c[0].pz[0];
+      }
+      if (whichA) c[0].key[1] = 0xFFFFFFFFu; else c[0].key[0] = 0xFFFFFFFFu;
+    }
+    if (lane == ownerB) {
+      sIdx1[i] = (long long)(whichB ? c[1].cidx[1] : c[1].cidx[0]);
+      sGIdx1[i] = (long long)(whichB ? c[1].gidx[1] : c[1].gidx[0]);
+      sD21[i] = __uint_as_float(bestB);
+      if (sPos1) {
+        sPos1[3 * i] = whichB ? c[1].px[1] : c[1].px[0];
+        sPos1[3 * i + 1] = whichB ? c[1].py[1] : c[1].py[0];
+        sPos1[3 * i + 2] = whichB ? c[1].pz[1] : c[1].pz[0];
+      }
+      if (whichB) c[1].key[1] = 0xFFFFFFFFu; else c[1].key[0] = 0xFFFFFFFFu;
+    }
+  }
+}
+
 // Search + selection for one query (whole wave), nothing prefetched.
 __device__ inline int knn_one_query(const pings_knn_map& m, const LaneCtx& lc, float qx, float qy, float qz,
                                     int lane, long long* sIdx, float* sD2, long long* sGIdx, float* sPos = nullptr) {

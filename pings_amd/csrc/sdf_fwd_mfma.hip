@@ -117,6 +117,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, IN_PAD > 36 ? 2 : 4) void sdf
         }
         Cand32 c[SQ];
         candidates_blocks_multi<SQ>(m, lc, qq, c);
+        if (SQ == 2) {
+          int cnt0, cnt1;
+          Cand32 (&c2)[2] = reinterpret_cast<Cand32 (&)[2]>(c);
+          select_topk32_pair(m, c2, lane, sIdx[wave] + NBR * j, sD2[wave] + NBR * j, sGIdx[wave] + NBR * j,
+                             sPos[wave] + 3 * NBR * j, sIdx[wave] + NBR * (j + 1), sD2[wave] + NBR * (j + 1),
+                             sGIdx[wave] + NBR * (j + 1), sPos[wave] + 3 * NBR * (j + 1), cnt0, cnt1);
+          if (lane == 0) { sCnt[wave][j] = cnt0; sCnt[wave][j + 1] = cnt1; }
+          continue;
+        }
 #pragma unroll
         for (int u = 0; u < SQ; ++u) {
           const int count = select_topk32(m, c[u], lane, sIdx[wave] + NBR * (j + u), sD2[wave] + NBR * (j + u),
