@@ -592,28 +592,52 @@ class _QfTable(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return None, None, None
-        L = _L()
-        st = ctx.st
-        F = st.Fc if ctx.which else st.Fg
-        dev = g.device
-        n_pairs = st.B * st.nn_k
-        if st.plan is None:
-            plan = torch.empty(L.pings_rows_plan_bytes(n_pairs, st.rows), dtype=torch.uint8, device=dev)
-            _lib.check(L.pings_rows_plan_build(_lib.ptr(st.idx), n_pairs, st.rows, _lib.ptr(plan), _lib.stream_ptr(dev)),
-                       "pings_rows_plan_build")
-            st.plan = plan
-        g = g.detach()
-        if g.dtype != torch.float32:
-            g = g.to(torch.float32)
-        # usually a strided view [B, k, F] of the contiguous [B, k, F+3] upstream gradient: read it where it lies
-        ld = g.stride(1) if g.dim() == 3 else 0
-        if not (g.dim() == 3 and g.stride(2) == 1 and g.stride(0) == st.nn_k * ld and ld >= F):
-            g = g.reshape(st.B, st.nn_k, F).contiguous()
-            ld = F
-        out = torch.empty(st.rows, F, dtype=torch.float32, device=dev)
-        _lib.check(L.pings_rows_plan_apply(_lib.ptr(st.plan), n_pairs, st.rows, g.data_ptr(), ld, F, None,
-                                           _lib.ptr(out), _lib.stream_ptr(dev)), "pings_rows_plan_apply")
-        return out, None, None
+        return _table_grad(ctx.st, ctx.which, g), None, None
+
+
+def _table_grad(st: _QfState, which: int, g: torch.Tensor) -> torch.Tensor:
+    """Deterministic row scatter-add of the upstream rows `g` ([B, k, F] or the first F columns of [B, k, F+3]) into a
+    dense [rows, F] table gradient (`pings_rows_plan_build` once per batch, `_apply` per table)."""
+    L = _L()
+    F = st.Fc if which else st.Fg
+    dev = g.device
+    n_pairs = st.B * st.nn_k
+    if st.plan is None:
+        plan = torch.empty(L.pings_rows_plan_bytes(n_pairs, st.rows), dtype=torch.uint8, device=dev)
+        _lib.check(L.pings_rows_plan_build(_lib.ptr(st.idx), n_pairs, st.rows, _lib.ptr(plan), _lib.stream_ptr(dev)),
+                   "pings_rows_plan_build")
+        st.plan = plan
+    g = g.detach()
+    if g.dtype != torch.float32:
+        g = g.to(torch.float32)
+    # usually a strided view [B, k, F] of the contiguous [B, k, F+3] upstream gradient: read it where it lies
+    ld = g.stride(1) if g.dim() == 3 else 0
+    if not (g.dim() == 3 and g.stride(2) == 1 and g.stride(0) == st.nn_k * ld and ld >= F):
+        g = g.reshape(st.B, st.nn_k, -1)[..., :F].contiguous()
+        ld = F
+    out = torch.empty(st.rows, F, dtype=torch.float32, device=dev)
+    _lib.check(L.pings_rows_plan_apply(_lib.ptr(st.plan), n_pairs, st.rows, g.data_ptr(), ld, F, None,
+                                       _lib.ptr(out), _lib.stream_ptr(dev)), "pings_rows_plan_apply")
+    return out
+
+
+class _QfRows(torch.autograd.Function):
+    """feature table -> the whole [B, k, F+3] rows in ONE node, for queries that carry no gradient themselves (the
+    mapper's sample points, mapper.py:848-866): the neighbour-vector columns are constants then, so the
+    _QfGeom / _QfTable / _QfInterleave split (which exists for d/dx) is two autograd nodes and ~40 us of Python too
+    many per step at the reference's batch size."""
+
+    @staticmethod
+    def forward(ctx, tab, st: _QfState, which: int):
+        ctx.st, ctx.which = st, which
+        return st.col_buf if which else st.geo_buf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        return _table_grad(ctx.st, ctx.which, g), None, None
 
 
 class _QfInterleave(torch.autograd.Function):
@@ -654,6 +678,17 @@ def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = Non
             bool(query_color_feature), bool(use_only_measured_points), bool(use_only_valid_points))
     if bool(cfg.weighted_first):
         return _QueryFeature.apply(query_points, feats, cfeats, self, opts)
+    if not (torch.is_grad_enabled() and query_points.requires_grad):
+        # no gradient to the query: run the kernel outside autograd, one node per table that wants a gradient
+        with torch.no_grad():
+            st, _, _, w, _, cnt, cert = _qf_forward(query_points, feats, cfeats, self, opts, want_n=False)
+        track = torch.is_grad_enabled()
+        geo = col = None
+        if st.has_geo:
+            geo = _QfRows.apply(feats, st, 0) if (track and feats.requires_grad) else st.geo_buf
+        if st.has_color:
+            col = _QfRows.apply(cfeats, st, 1) if (track and cfeats.requires_grad) else st.col_buf
+        return geo, col, w.unsqueeze(-1), cnt, cert
     box = []
     n, w, cnt, cert = _QfGeom.apply(query_points, feats.detach() if feats is not None else None,
                                     cfeats.detach() if cfeats is not None else None, self, opts, box)
