@@ -445,6 +445,23 @@ def test_hip_query_feature_first_and_second_order_gradients_match_oracle(golden_
                               lambda m, x, ts, **kw: hnp.query_feature(m, x, ts, **kw))
     for a, b in zip(got1, again1):
         assert torch.equal(a, b)
+    # a query without a gradient of its own (the mapper's sample points) takes the one-node path: same outputs, same
+    # table gradients, bit for bit
+    rw = torch.Generator().manual_seed(11)
+    outs = []
+    for needs_x in (True, False):
+        xq = T(st["x"]).cuda().requires_grad_(needs_x)
+        geo, col, w, cnt, cert = hnp.query_feature(gpu, xq, None, accumulate_stability=False, query_color_feature=True)
+        if not outs:
+            r_g = torch.randn(geo.shape, generator=rw).cuda()
+            r_c = torch.randn(col.shape, generator=rw).cuda()
+        loss = (geo * r_g).sum() + (col * r_c).sum()
+        outs.append((geo.detach(), col.detach(), w.detach(), cnt, cert,
+                     torch.autograd.grad(loss, [gpu.local_geo_features, gpu.local_color_features])))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][5], outs[1][5]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu
