@@ -58,11 +58,15 @@ def shard_batch(n: int, r: int = None, w: int = None) -> slice:
 class GradBucket:
     """Gradients of `params` in one persistent flat buffer; `p.grad` are views of it.
 
-    Per step: `zero()` (one memset; replaces `opt.zero_grad()` for these parameters) -> forward /
-    backward (autograd accumulates in place into the views; with `overlap=True` the all-reduce is
-    issued asynchronously the moment the last parameter of the bucket has received its gradient) ->
-    `finish()` before `opt.step()` (issues the collective if the hooks did not, waits, averages).
-    With world_size == 1 `finish()` returns immediately and no collective is ever created."""
+    Per step: `zero(n_backwards)` (one memset; replaces `opt.zero_grad()` for these parameters) -> `n_backwards`
+    forward / backward passes (autograd accumulates in place into the views; a rank that holds several views of a
+    frame, `views_for_rank`, runs one backward per view) -> `finish()` before `opt.step()` (issues the collective if
+    the hooks did not, waits, averages).  With `overlap=True` the all-reduce is issued asynchronously from a
+    post-accumulate hook the moment the LAST of the `n_backwards * len(params)` expected accumulations has happened —
+    never earlier: an all-reduce in flight while a later backward still adds into the buffer would reduce partial sums.
+    A gradient that reaches the bucket after its collective was launched (more backward passes than announced) makes
+    `finish()` raise instead of returning a racy sum.  With world_size == 1 `finish()` returns immediately and no
+    collective is ever created."""
 
     def __init__(self, params: Sequence[torch.Tensor], average: bool = True, overlap: bool = True):
         self.params = [p for p in params if p is not None and p.requires_grad]
@@ -74,30 +78,47 @@ class GradBucket:
         self.average = average
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
         self.views = []
+        self._view_of = {}
         off = 0
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
             self.views.append(v)
+            self._view_of[id(p)] = v
             p.grad = v
         self._pending = 0
         self._work = None
+        self._late = 0
         self._hooks = []
         if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # -- per step
-    def zero(self) -> None:
+    def zero(self, n_backwards: int = 1) -> None:
+        """Clear the bucket for a step of `n_backwards` backward passes (one per view this rank renders)."""
+        if n_backwards < 1:
+            raise ValueError("GradBucket.zero: n_backwards must be >= 1")
+        if self._work is not None:
+            raise RuntimeError("GradBucket.zero() while an all-reduce is in flight: call finish() first")
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v                      # someone ran zero_grad(set_to_none=True): re-attach the view
-        self._pending = len(self.params)
-        self._work = None
+        self._pending = n_backwards * len(self.params)
+        self._late = 0
 
     def _on_grad(self, p: torch.Tensor) -> None:
         if world() == 1:
+            return
+        v = self._view_of[id(p)]
+        g = p.grad
+        if g is not None and g.data_ptr() != v.data_ptr():     # accumulated outside the view (p.grad was None)
+            if self._work is None:
+                v.add_(g)
+            p.grad = v
+        if self._work is not None:              # the collective is already travelling: this sum cannot be repaired
+            self._late += 1
             return
         self._pending -= 1
         if self._pending == 0:
@@ -112,12 +133,19 @@ class GradBucket:
         w = world()
         if w == 1:
             return
-        for p, v in zip(self.params, self.views):
-            g = p.grad
-            if g is not None and g.data_ptr() != v.data_ptr():   # a gradient that arrived outside the view
-                v.copy_(g)
-                p.grad = v
-        self._launch()                          # parameters this view never touched: hooks did not fire
+        if self._late:
+            self._work.wait()
+            self._work = None
+            raise RuntimeError(
+                f"GradBucket: {self._late} gradient accumulation(s) arrived after the all-reduce had been launched "
+                "(more backward passes than zero(n_backwards=...) announced); the reduced values are not usable")
+        if self._work is None:
+            for p, v in zip(self.params, self.views):
+                g = p.grad
+                if g is not None and g.data_ptr() != v.data_ptr():   # a gradient that arrived outside the view
+                    v.add_(g)
+                    p.grad = v
+            self._launch()                      # parameters some view never touched: the hooks did not count to zero
         self._work.wait()
         self._work = None
         if self.average:
@@ -130,52 +158,82 @@ class GradBucket:
 
 
 # ------------------------------------------------------------------ row-sparse exchange
+_META_GROUP = {}
+
+
+def _meta_group(device: torch.device):
+    """Process group for HOST-side metadata (row counts): the default group when it is a CPU backend, else one gloo
+    group created once (collectively) next to the RCCL one.  Counts exchanged here never touch the HIP stream."""
+    if device.type == "cpu" or dist.get_backend() == "gloo":
+        return None
+    g = _META_GROUP.get("g")
+    if g is None:
+        g = _META_GROUP["g"] = dist.new_group(backend="gloo")
+    return g
+
+
+def _sum_rows(dst_row: torch.Tensor, src: torch.Tensor, col0: int, F: int, N: int) -> torch.Tensor:
+    """out[r] = sum over pairs p (ascending) with dst_row[p] == r of src[p, col0:col0+F]; pairs with dst_row < 0 are
+    padding.  On the HIP device this is `pings_rows_scatter_add` (counting sort + fixed-order sums: the same bits on
+    every rank whatever the arrival order); on the host `index_add_` is sequential, hence also ordered."""
+    if src.is_cuda:
+        from . import neural_points as _np
+
+        return _np.rows_scatter_add(dst_row, src[:, col0:], N, F=F)
+    out = torch.zeros(N, F, dtype=src.dtype, device=src.device)
+    keep = dst_row >= 0
+    out.index_add_(0, dst_row[keep], src[keep][:, col0:col0 + F])
+    return out
+
+
 class RowSparseExchange:
     """Mean over ranks of a row-sparse gradient table `grad[N, F]` given the rows each rank touched.
 
-    all-gather of the row counts, then two concurrent all-gathers of the padded row indices (int64) and gradient
-    rows; every rank then adds all ranks' rows in rank order with `index_add_` on unique indices — deterministic
-    and bit-identical everywhere.  Dense all-reduce instead when max_rows * world >= dense_threshold * N (a ring
-    all-reduce moves 2 (w-1)/w of the table per rank, the gather (w-1) x the padded rows)."""
+    One step = (1) the ranks' row counts travel over a host-side (gloo) group — every count is a host value already
+    (`rows.numel()`, or the visible count `render` has read back), so nothing waits for the HIP stream; (2) ONE
+    `all_gather_into_tensor` of a packed `[m, 1 + F]` buffer per rank (column 0 = the row index as int32 bits, −1 in
+    the padding up to the largest count m; columns 1.. = the gradient row): geo and colour features travel as one
+    `[N, 48]` table; (3) one deterministic sum of all ranks' rows in (rank, row) order into the dense table
+    (`_sum_rows`) — bit-identical on every rank.  Dense all-reduce instead when the gather would send at least
+    `dense_threshold` x the bytes of a ring all-reduce (per rank: (w-1) x the padded rows against 2 (w-1)/w of the
+    table; 0.75 by default: the compaction and the scatter-sum cost two more passes over the rows)."""
 
-    def __init__(self, dense_threshold: float = 1.0):
+    def __init__(self, dense_threshold: float = 0.75):
         self.dense_threshold = dense_threshold
         self.last = {}
 
-    def reduce_(self, grad: torch.Tensor, rows: torch.Tensor, average: bool = True) -> torch.Tensor:
-        """In place on `grad` ([N, F], zero outside `rows`); `rows` = sorted unique int64 indices this rank wrote."""
+    def reduce_(self, grad: torch.Tensor, rows: torch.Tensor, average: bool = True, n_rows: int = None) -> torch.Tensor:
+        """In place on `grad` ([N, F], zero outside `rows`); `rows` = unique int64 indices this rank wrote (its first
+        `n_rows` entries when given: a worst-case-sized index buffer with a host-known count)."""
         w = world()
         if w == 1:
             return grad
         N, F = grad.shape
-        n_loc = torch.tensor([rows.numel()], dtype=torch.int64, device=grad.device)
-        counts = [torch.zeros_like(n_loc) for _ in range(w)]
-        dist.all_gather(counts, n_loc)
-        counts = [int(c.item()) for c in counts]
+        k = int(rows.numel() if n_rows is None else n_rows)
+        mine = torch.tensor([k], dtype=torch.int64)
+        counts_t = torch.empty(w, dtype=torch.int64)
+        dist.all_gather_into_tensor(counts_t, mine, group=_meta_group(grad.device))
+        counts = counts_t.tolist()
         m = max(counts)
         self.last = {"rows_per_rank": counts, "table_rows": N, "mode": "sparse"}
-        if m * w >= self.dense_threshold * N:
+        gather_bytes = (w - 1) * m * (1 + F)                    # sent per rank by the padded all-gather (x4 B)
+        ring_bytes = 2.0 * (w - 1) / w * N * F                  # sent per rank by a ring all-reduce of the dense table
+        if gather_bytes >= self.dense_threshold * ring_bytes:
             self.last["mode"] = "dense"
             dist.all_reduce(grad)
             if average:
                 grad.div_(w)
             return grad
-        idx_pad = torch.zeros(m, dtype=torch.int64, device=grad.device)
-        val_pad = torch.zeros(m, F, dtype=grad.dtype, device=grad.device)
-        k = rows.numel()
-        idx_pad[:k] = rows
-        val_pad[:k] = grad[rows]
-        idx_all = [torch.empty_like(idx_pad) for _ in range(w)]
-        val_all = [torch.empty_like(val_pad) for _ in range(w)]
-        h1 = dist.all_gather(idx_all, idx_pad, async_op=True)
-        h2 = dist.all_gather(val_all, val_pad, async_op=True)
-        h1.wait()
-        h2.wait()
-        grad.zero_()
-        for r_ in range(w):                      # rank order, own rows included: the same sum on every rank
-            c = counts[r_]
-            if c:
-                grad.index_add_(0, idx_all[r_][:c], val_all[r_][:c])
+        pack = torch.empty(m, 1 + F, dtype=torch.float32, device=grad.device)
+        idx_col = pack.view(torch.int32)[:, 0]
+        idx_col[:k] = rows[:k].to(torch.int32)
+        idx_col[k:] = -1
+        pack[:k, 1:] = grad[rows[:k]]
+        pack[k:, 1:] = 0.0
+        gathered = torch.empty(w * m, 1 + F, dtype=torch.float32, device=grad.device)
+        dist.all_gather_into_tensor(gathered, pack)
+        dst = gathered.view(torch.int32)[:, 0].to(torch.int64)
+        grad.copy_(_sum_rows(dst, gathered, 1, F, N))
         if average:
             grad.div_(w)
         return grad

@@ -312,7 +312,11 @@ def rows_scatter_add(dst_row: torch.Tensor, src: torch.Tensor, rows: int, w: tor
     """out[r] = sum over pairs p with dst_row[p] == r (ascending p) of w[p] * src[src_row[p], :F]; [rows, F], bitwise
     reproducible (`pings_rows_scatter_add`: the backward of a row gather without float atomics)."""
     L = _L()
-    src2 = src.reshape(-1, src.shape[-1]).contiguous()
+    if src.dim() == 2 and src.stride(1) == 1 and src.stride(0) >= src.shape[1] and src.is_cuda:
+        src2, ld = src, int(src.stride(0))          # a column slice of a row-major table is read where it lies
+    else:
+        src2 = src.reshape(-1, src.shape[-1]).contiguous()
+        ld = int(src2.shape[1])
     F = int(src2.shape[1] if F is None else F)
     dst = dst_row.reshape(-1).to(torch.int64).contiguous()
     n = dst.shape[0]
@@ -320,7 +324,9 @@ def rows_scatter_add(dst_row: torch.Tensor, src: torch.Tensor, rows: int, w: tor
     scratch = torch.empty(L.pings_rows_scatter_add_scratch_bytes(n, rows), dtype=torch.uint8, device=src.device)
     wv = w.reshape(-1).to(torch.float32).contiguous() if w is not None else None
     sr = src_row.reshape(-1).to(torch.int64).contiguous() if src_row is not None else None
-    _lib.check(L.pings_rows_scatter_add(_lib.ptr(dst), n, _lib.ptr(src2), int(src2.shape[1]), F, _lib.ptr(wv),
+    if not src2.is_cuda:
+        raise _lib.PingsHipError("rows_scatter_add runs on the HIP device only (no CPU fallback)")
+    _lib.check(L.pings_rows_scatter_add(_lib.ptr(dst), n, src2.data_ptr(), ld, F, _lib.ptr(wv),
                                         _lib.ptr(sr), rows, _lib.ptr(scratch), _lib.ptr(out),
                                         _lib.stream_ptr(src.device)), "pings_rows_scatter_add")
     return out

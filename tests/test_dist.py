@@ -171,3 +171,136 @@ def test_world_size_one_bucket_step_is_bit_identical_to_plain_step():
     for a, p in zip(plain, [feats, cfeats] + mlp):
         assert torch.equal(a, p.grad)
     assert b._work is None
+
+
+# ------------------------------------------------------------------ several views per rank (premature launch)
+def _worker3(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        views = pdist.views_for_rank(4)                              # two views per rank: two backward() per step
+        # (a) reference: gradients accumulated by autograd, one-shot all-reduce afterwards
+        feats, cfeats, mlp = _make_model()
+        for v in views:
+            _view_loss(feats, cfeats, mlp, v)[0].backward()
+        pdist.allreduce_grads([feats, cfeats] + mlp)
+        ref = [p.grad.clone() for p in [feats, cfeats] + mlp]
+        # (b) hook-fired bucket told about both backward passes: the collective must not start after the first one
+        feats, cfeats, mlp = _make_model()
+        b = pdist.GradBucket([feats, cfeats] + mlp, overlap=True)
+        launched_after_first = []
+        for step in range(2):
+            b.zero(n_backwards=len(views))
+            for i, v in enumerate(views):
+                _view_loss(feats, cfeats, mlp, v)[0].backward()
+                if i == 0:
+                    launched_after_first.append(b._work is not None)
+            fired_by_hook = b._work is not None
+            b.finish()
+        out = [p.grad.clone() for p in [feats, cfeats] + mlp]
+        # (c) a backward pass the bucket was not told about: finish() must refuse the racy sum
+        b.zero(n_backwards=1)
+        for v in views:
+            _view_loss(feats, cfeats, mlp, v)[0].backward()
+        try:
+            b.finish()
+            raised = False
+        except RuntimeError as e:
+            raised = "after the all-reduce had been launched" in str(e)
+        # (d) zero_grad(set_to_none=True) between steps: the hook folds the stray gradient back into the view
+        for p in [feats, cfeats] + mlp:
+            p.grad = None
+        b._pending, b._late = 2 * len(b.params), 0
+        b.flat.zero_()
+        for v in views:
+            _view_loss(feats, cfeats, mlp, v)[0].backward()
+        b.finish()
+        out_d = [p.grad.clone() for p in [feats, cfeats] + mlp]
+        q.put((rank, [g.numpy() for g in ref], [g.numpy() for g in out], launched_after_first, fired_by_hook, raised,
+               [g.numpy() for g in out_d]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_views_per_rank_bucket_waits_for_the_last_backward():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ref, out, early, fired, raised, out_d in res:
+        assert early == [False, False]          # nothing in flight while the second backward still accumulates
+        assert fired                            # ... and the hooks did launch it once the last gradient was in
+        assert raised
+        for a, r in zip(out, ref):
+            assert (a == r).all()
+        for a, r in zip(out_d, ref):
+            assert (a == r).all()
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a == b).all()
+
+
+# ------------------------------------------------------------------ C4 shape: 4 cameras, one per rank
+def _worker4(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (view,) = pdist.views_for_rank(4)
+        # dense reference on every rank
+        feats, cfeats, mlp = _make_model()
+        _view_loss(feats, cfeats, mlp, view)[0].backward()
+        pdist.allreduce_grads([feats, cfeats] + mlp)
+        dense = [p.grad.clone() for p in [feats, cfeats] + mlp]
+        # product schedule: decoder bucket fired from the hooks, geo + colour rows as ONE [N, 12] table, row-sparse
+        feats, cfeats, mlp = _make_model()
+        b_mlp = pdist.GradBucket(mlp, overlap=True)
+        b_tab = pdist.GradBucket([feats, cfeats], overlap=False)
+        ex = pdist.RowSparseExchange()
+        b_mlp.zero()
+        b_tab.zero()
+        loss, idx = _view_loss(feats, cfeats, mlp, view)
+        loss.backward()
+        tab = torch.cat([feats.grad, cfeats.grad], 1)
+        worst = torch.cat([idx, torch.zeros(17, dtype=torch.int64)])    # worst-case sized index buffer + host count
+        ex.reduce_(tab, worst, n_rows=idx.numel())
+        b_mlp.finish()
+        q.put((rank, [g.numpy() for g in dense], tab.numpy(), [p.grad.numpy() for p in mlp], dict(ex.last)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_cameras_on_four_ranks_sparse_table_and_hooked_bucket():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the single-GPU schedule: four backward passes one after the other, summed, divided by the view count
+    feats, cfeats, mlp = _make_model()
+    for v in range(4):
+        _view_loss(feats, cfeats, mlp, v)[0].backward()
+    seq = [p.grad / 4 for p in [feats, cfeats] + mlp]
+    seq_tab = torch.cat(seq[:2], 1).numpy()
+    for _, dense, tab, g_mlp, last in res:
+        assert last["mode"] == "sparse" and last["rows_per_rank"] == [60, 60, 60, 60]
+        assert (tab == res[0][2]).all()                                 # identical bits on every rank
+        assert (tab[:, :8] == dense[0]).all() and (tab[:, 8:] == dense[1]).all()   # rows have <= 2 contributors: exact
+        assert (tab == seq_tab).all()
+        for a, a0, d, s in zip(g_mlp, res[0][3], dense[2:], seq[2:]):
+            assert (a == a0).all()                                      # identical bits on every rank
+            # a ring all-reduce sums an element in an order that depends on where it lies in the buffer, and the
+            # bucket's buffer is not the one-shot call's: equal up to fp32 summation order
+            assert abs(a - d).max() <= 1e-5 * max(1.0, abs(d).max())
+            assert abs(a - s.numpy()).max() <= 1e-5 * max(1.0, abs(s.numpy()).max())
