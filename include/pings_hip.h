@@ -127,6 +127,18 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                                       const float* scales, const float* rotations,
                                       void* geom_blob, int32_t* radii, int64_t* num_instances,
                                       int32_t* footprint_class, void* stream);
+/* The same for a frame whose producer kernels left row counts on the DEVICE (`render`, gaussian_renderer/__init__.py:
+ * 219,305,563-569,730-737 are four host synchronisations in the reference; this call is the one of the frame here):
+ * of the first `dyn_rows` Gaussians only rows [0, *live_rows_dev) exist (the rest of that worst-case sized block is
+ * culled without being read); rows [dyn_rows, P) are ordinary.  live_rows_dev NULL = every row exists.
+ * aux_dev: HOST array of up to 8 DEVICE pointers to int32 words (NULL entries read as 0) that are copied to the HOST
+ * array aux_host in the same read-back as the instance count. */
+PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P, const float* means3D,
+                                          const float* colors, const float* opacities, const float* scales,
+                                          const float* rotations, void* geom_blob, int32_t* radii,
+                                          const int32_t* live_rows_dev, int dyn_rows,
+                                          const int32_t* const* aux_dev, int aux_words, int32_t* aux_host,
+                                          int64_t* num_instances, int32_t* footprint_class, void* stream);
 
 /* Stage 2: instance binning (stable tile sort) and per-tile alpha blending.
  * Outputs are planar [C,H,W].  out_normal may be NULL in 3DGS mode.  `per_gaussian`
@@ -421,6 +433,9 @@ typedef struct pings_mlp_job {
   float *dL_dW1, *dL_db1, *dL_dW2, *dL_db2;
 } pings_mlp_job;
 PINGS_API int pings_mlp_forward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* stream);
+/* N sizes the buffers and the grid; *n_rows_dev (device int32, NULL = N) rows are decoded, the rest is not touched. */
+PINGS_API int pings_mlp_forward_grouped_dyn(const pings_mlp_job* jobs, int njobs, int64_t N, const int32_t* n_rows_dev,
+                                            void* stream);
 PINGS_API size_t pings_mlp_backward_grouped_scratch_bytes(const pings_mlp_job* jobs, int njobs);
 PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* scratch,
                                          void* stream);
@@ -472,6 +487,28 @@ PINGS_API int pings_spawn_gather(int n, const int64_t* sel, const float* positio
                                  int view_concat, int dist_concat, float* pos, float* quat, float* base_color,
                                  uint8_t* free_out, float* geo_in, float* col_in, float* view_dist,
                                  void* stream);
+/* `_dyn` forms of gather / plan / forward: `n` (p->n) is the CAPACITY the buffers and grids are sized for and
+ * *n_rows_dev (device int32; NULL = n) the rows the visible & valid mask actually selected (a count `render` no longer
+ * reads back before spawning, gaussian_renderer/__init__.py:563-569): rows behind it are neither read nor written,
+ * never kept by the plan, and the free-mask tiling (:724) uses the device count.  nan_flag (device int32, nullable):
+ * zeroed by the plan, set to 1 by the forward when a spawned rotation is NaN (the reference's assert, :305-306). */
+PINGS_API int pings_spawn_gather_dyn(int n, const int32_t* n_rows_dev, const int64_t* sel, const float* position,
+                                     const float* orientation, const float* color, const uint8_t* free_mask,
+                                     const float* geo_feature, int Fg, const float* color_feature, int Fc,
+                                     const float* cam_origin, int xy_only, int view_concat, int dist_concat,
+                                     float* pos, float* quat, float* base_color, uint8_t* free_out, float* geo_in,
+                                     float* col_in, float* view_dist, void* stream);
+PINGS_API int pings_spawn_plan_dyn(const pings_spawn_params* p, const int32_t* n_rows_dev, const float* alpha_raw,
+                                   const float* scale_raw, const float* dist_ratio, void* scratch, int32_t* dest,
+                                   int32_t* count, int32_t* nan_flag, void* stream);
+PINGS_API int pings_spawn_forward_dyn(const pings_spawn_params* p, const int32_t* n_rows_dev, const float* xyz_raw,
+                                      const float* rot_raw, const float* scale_raw, const float* alpha_raw,
+                                      const float* color_raw, const float* pos, const float* quat,
+                                      const float* base_color, const float* dist_ratio, const uint8_t* free_in,
+                                      const int32_t* dest, float* gaussian_xyz, float* gaussian_scale,
+                                      float* gaussian_rot, float* gaussian_alpha, float* gaussian_color,
+                                      float* alpha_all, uint8_t* gaussian_free_mask, int32_t* nan_flag,
+                                      void* stream);
 /* Scatter of the per-view feature gradients (leading dimensions ldg / ldc, first Fg / Fc columns) into
  * rows `sel` of the map-sized, PRE-ZEROED gradient tensors.  Either pair may be NULL. */
 PINGS_API int pings_spawn_gather_backward(int n, const int64_t* sel, const float* dL_dgeo_in, int Fg, int ldg,

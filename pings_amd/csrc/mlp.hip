@@ -284,8 +284,10 @@ struct MlpJobs {
   int IN[MAX_JOBS], OUT[MAX_JOBS];
 };
 
-__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_grouped_kernel(long long N, MlpJobs j) {
+__global__ __launch_bounds__(256, 2) void mlp_fwd_wave_grouped_kernel(long long N, MlpJobs j,
+                                                                      const int* __restrict__ n_dev) {
   const int g = blockIdx.y;
+  if (n_dev) N = min(N, (long long)*n_dev);   // N sized the grid and the buffers; the rows to decode are counted on the device
   mlp_fwd_wave_body(N, j.IN[g], j.OUT[g], j.x[g], j.W1[g], j.b1[g], j.W2[g], j.b2[g], j.y[g]);
 }
 
@@ -1079,6 +1081,11 @@ int fill_jobs(const pings_mlp_job* jobs, int njobs, MlpJobs& J) {
 }  // namespace
 
 PINGS_API int pings_mlp_forward_grouped(const pings_mlp_job* jobs, int njobs, int64_t N, void* stream) {
+  return pings_mlp_forward_grouped_dyn(jobs, njobs, N, nullptr, stream);
+}
+
+PINGS_API int pings_mlp_forward_grouped_dyn(const pings_mlp_job* jobs, int njobs, int64_t N, const int32_t* n_rows_dev,
+                                            void* stream) {
   MlpJobs J;
   if (int e = fill_jobs(jobs, njobs, J)) return e;
   PINGS_ARG_CHECK(N >= 0, "negative N");
@@ -1091,7 +1098,8 @@ PINGS_API int pings_mlp_forward_grouped(const pings_mlp_job* jobs, int njobs, in
   const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
   const long long cap = 512 / njobs;   // floor: one workgroup too many would run alone in a second round
   const unsigned grid_w = (unsigned)(want < cap ? want : cap);
-  hipLaunchKernelGGL(mlp_fwd_wave_grouped_kernel, dim3(grid_w, njobs), dim3(256), 0, st, (long long)N, J);
+  hipLaunchKernelGGL(mlp_fwd_wave_grouped_kernel, dim3(grid_w, njobs), dim3(256), 0, st, (long long)N, J,
+                     (const int*)n_rows_dev);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

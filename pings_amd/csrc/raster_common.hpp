@@ -67,6 +67,12 @@ struct Carver {
   }
 };
 
+struct FrameSummary {   // the record of a frame's one host read-back (frame_summary_kernel)
+  uint32_t total, overflow;
+  unsigned long long stats[3];
+  int32_t aux[8];
+};
+
 struct GeomState {
   float4* rec;
   uint4* rect;
@@ -81,6 +87,7 @@ struct GeomState {
   size_t ds_words;                          //   [DS_NB + blocks + 1] their exclusive scan; ds_words = memset extent
   uint32_t* ds_idx;                         //   [P] Gaussian ids in bucket order (keys go to depth_key_sorted)
   unsigned long long* stats;                // [2] pairs before occlusion culling, visible Gaussians
+  FrameSummary* summary;
   int occ_nb;
   char* temp;
   size_t temp_bytes;

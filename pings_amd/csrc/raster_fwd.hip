@@ -41,6 +41,8 @@ struct KParams {
   const float* proj_raw;
   const float* bg;
   const float* prcp;
+  const int32_t* live;   // device word: of the first `dyn_rows` Gaussians only rows [0, *live) exist (nullable)
+  int dyn_rows;
 };
 
 // ---------------------------------------------------------------- blob carving
@@ -95,6 +97,7 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.ds_off = c.take<uint32_t>((size_t)DS_NB + nblk + 1);
   g.ds_idx = c.take<uint32_t>(n);
   g.stats = c.take<unsigned long long>(3 * 256);  // sharded {pairs before culling, visible Gaussians, kept pairs}
+  g.summary = c.take<FrameSummary>(1);            // what the frame's one read-back fetches
   g.temp_bytes = sort_temp_bytes((int64_t)n);
   g.temp = c.take<char>(g.temp_bytes);
   g.total = c.off;
@@ -189,6 +192,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   float px, py, pz;
   to_camera(V, means3D[3 * g], means3D[3 * g + 1], means3D[3 * g + 2], px, py, pz);
   bool ok = pz > NEAR_Z;
+  // rows of a worst-case sized buffer behind the count the producer left on the device: culled (their contents are
+  // never interpreted: every use below is guarded by `ok`)
+  if (p.live && g < p.dyn_rows && g >= *p.live) ok = false;
 
   const float hx = ((Pm[0] * px + Pm[4] * py) + Pm[8] * pz) + Pm[12];
   const float hy = ((Pm[1] * px + Pm[5] * py) + Pm[9] * pz) + Pm[13];
@@ -1846,6 +1852,34 @@ __global__ __launch_bounds__(256) void per_gaussian_sum_kernel(
   if (g < P) out[g] = sum;
 }
 
+// One wave folds everything the host reads at the frame's one synchronisation into a 64-byte record: instance total,
+// depth-sort overflow flag, the three sharded statistics and up to 8 caller words (counts other kernels of the frame
+// left on the device: pings_raster_preprocess_dyn).
+struct AuxPtrs {
+  const int32_t* p[8];
+};
+__global__ __launch_bounds__(64) void frame_summary_kernel(const uint32_t* __restrict__ last_offset,
+                                                           const uint32_t* __restrict__ overflow,
+                                                           const unsigned long long* __restrict__ shards, AuxPtrs aux,
+                                                           int aux_words, FrameSummary* __restrict__ out) {
+  __shared__ unsigned long long part[3][64];
+  const int lane = threadIdx.x;
+  unsigned long long a0 = 0, a1 = 0, a2 = 0;
+  for (int i = lane; i < STAT_SHARDS; i += 64) {
+    a0 += shards[3 * i]; a1 += shards[3 * i + 1]; a2 += shards[3 * i + 2];
+  }
+  part[0][lane] = a0; part[1][lane] = a1; part[2][lane] = a2;
+  __syncthreads();
+  if (lane < 3) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 64; ++i) t += part[lane][i];
+    out->stats[lane] = t;
+  }
+  if (lane == 3) out->total = *last_offset;
+  if (lane == 4) out->overflow = overflow ? *overflow : 0u;
+  if (lane >= 8 && lane < 16) out->aux[lane - 8] = (lane - 8 < aux_words && aux.p[lane - 8]) ? *aux.p[lane - 8] : 0;
+}
+
 static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   PINGS_ARG_CHECK(s != nullptr, "null settings");
   PINGS_ARG_CHECK(s->image_height > 0 && s->image_width > 0, "empty image");
@@ -1870,6 +1904,8 @@ static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   kp.proj_raw = s->projmatrix_raw;
   kp.bg = s->bg;
   kp.prcp = s->prcppoint;
+  kp.live = nullptr;
+  kp.dyn_rows = 0;
   return PINGS_OK;
 }
 
@@ -1920,12 +1956,27 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
                                       const float* scales, const float* rotations,
                                       void* geom_blob, int32_t* radii, int64_t* num_instances,
                                       int32_t* footprint_class, void* stream) {
+  return pings_raster_preprocess_dyn(s, P, means3D, colors, opacities, scales, rotations, geom_blob, radii, nullptr, 0,
+                                     nullptr, 0, nullptr, num_instances, footprint_class, stream);
+}
+
+PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P, const float* means3D,
+                                          const float* colors, const float* opacities, const float* scales,
+                                          const float* rotations, void* geom_blob, int32_t* radii,
+                                          const int32_t* live_rows_dev, int dyn_rows,
+                                          const int32_t* const* aux_dev, int aux_words, int32_t* aux_host,
+                                          int64_t* num_instances, int32_t* footprint_class, void* stream) {
   KParams kp;
   if (int e = make_params(s, P, kp)) return e;
   PINGS_ARG_CHECK(num_instances != nullptr && footprint_class != nullptr, "null output");
   *num_instances = 0;
   *footprint_class = 1;
+  PINGS_ARG_CHECK(aux_words >= 0 && aux_words <= 8 && (aux_words == 0 || (aux_dev && aux_host)), "0..8 aux words");
+  PINGS_ARG_CHECK(!live_rows_dev || (dyn_rows >= 0 && dyn_rows <= P), "dyn_rows must lie in 0..P");
+  PINGS_ARG_CHECK(P > 0 || aux_words == 0, "aux words need a non-empty frame");
   if (P == 0) return PINGS_OK;
+  kp.live = live_rows_dev;
+  kp.dyn_rows = live_rows_dev ? dyn_rows : 0;
   PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob && radii,
                   "null pointer");
   hipStream_t st = pings::as_stream(stream);
@@ -1948,8 +1999,13 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
   if (const char* e = getenv("PINGS_RASTER_OCCLUSION")) occlusion = atoi(e) != 0;
   bool library_sort = false;
   if (const char* e = getenv("PINGS_DEPTH_SORT")) library_sort = e[0] == 'l';
+  // the record of the frame's one read-back lands in pinned host memory: one truly asynchronous 64-byte copy and one
+  // stream synchronisation (three pageable copies, each a wait of its own, before)
+  static thread_local FrameSummary* host_sum = nullptr;
+  if (!host_sum) PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_sum), sizeof(FrameSummary), hipHostMallocDefault));
+  AuxPtrs aux;
+  for (int i = 0; i < 8; ++i) aux.p[i] = i < aux_words ? aux_dev[i] : nullptr;
   uint32_t total = 0;
-  static thread_local unsigned long long shards[3 * STAT_SHARDS];
   for (;;) {
     size_t tb = gs.temp_bytes;
     if (library_sort) {
@@ -2010,21 +2066,18 @@ PINGS_API int pings_raster_preprocess(const pings_raster_settings* s, int P, con
       PINGS_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(gs.temp, tb, gs.tiles_sorted, gs.offsets_sorted,
                                                        P, st));
     }
-    uint32_t overflow = 0;
-    PINGS_HIP_CHECK(hipMemcpyAsync(&total, gs.offsets_sorted + (P - 1), sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
-    PINGS_HIP_CHECK(hipMemcpyAsync(shards, gs.stats, sizeof(shards), hipMemcpyDeviceToHost, st));
-    if (!library_sort)
-      PINGS_HIP_CHECK(hipMemcpyAsync(&overflow, gs.ds_head + DS_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(frame_summary_kernel, dim3(1), dim3(64), 0, st, gs.offsets_sorted + (P - 1),
+                       library_sort ? (const uint32_t*)nullptr : gs.ds_head + DS_FLAG, gs.stats, aux, aux_words, gs.summary);
+    PINGS_LAUNCH_CHECK();
+    PINGS_HIP_CHECK(hipMemcpyAsync(host_sum, gs.summary, sizeof(FrameSummary), hipMemcpyDeviceToHost, st));
     PINGS_HIP_CHECK(hipStreamSynchronize(st));
-    if (overflow == 0) break;
+    total = host_sum->total;
+    if (host_sum->overflow == 0) break;
     library_sort = true;  // a depth bucket overflowed: redo the frame with the library sort
   }
   *num_instances = (int64_t)total;
-  unsigned long long stats[3] = {0, 0, 0};
-  for (int i = 0; i < STAT_SHARDS; ++i) {
-    stats[0] += shards[3 * i]; stats[1] += shards[3 * i + 1]; stats[2] += shards[3 * i + 2];
-  }
+  const unsigned long long stats[3] = {host_sum->stats[0], host_sum->stats[1], host_sum->stats[2]};
+  for (int i = 0; i < aux_words; ++i) aux_host[i] = host_sum->aux[i];
   PINGS_ARG_CHECK(stats[2] == (unsigned long long)total && stats[2] < 0x7FFFFFFFull,
                   "more than 2^31 - 1 (Gaussian, tile) instances in this frame");
   // Footprints of many tiles keep most lanes of a wave busy: two pixels per lane then amortise the per-record

@@ -56,6 +56,7 @@ struct GatherArgs {
   const uint8_t* free_mask;
   float *pos, *quat, *base, *geo_in, *col_in, *view_dist;
   uint8_t* free_out;
+  const int32_t* n_dev;   // rows actually selected (device word; `n` is then the capacity the grid was sized for)
 };
 
 // One 16-lane group per row (four rows per wave, no grid-stride loop: a wave that walks its rows one after the other
@@ -63,7 +64,8 @@ struct GatherArgs {
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
   const int lane = threadIdx.x & 15;
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (i >= a.n) return;   // whole groups leave together: the width-16 shuffles below stay inside live groups
+  const int n_rows = a.n_dev ? min(a.n, *a.n_dev) : a.n;
+  if (i >= n_rows) return;   // whole groups leave together: the width-16 shuffles below stay inside live groups
   const int64_t src = a.sel ? a.sel[i] : (int64_t)i;
   // small per-point attributes: lanes 0..2 position, 4..7 quaternion, 8..10 colour
   float pv = 0.f;
@@ -120,7 +122,11 @@ struct SpawnArgs {
   const float *pos, *quat, *base, *dist_ratio;
   const uint8_t* free_in;
   const int32_t* dest;  // compacted row per Gaussian, -1 = dropped; nullptr = identity
+  const int32_t* n_dev; // neural points actually selected (device word); p.n is then only the capacity
+  int32_t* nan_flag;    // set to 1 when a spawned rotation is NaN (nullable)
 };
+
+__device__ inline int rows_of(const SpawnArgs& a) { return a.n_dev ? min(a.p.n, *a.n_dev) : a.p.n; }
 
 __device__ inline void scales_of(const SpawnArgs& a, int64_t g, int i, float s[3], float e[3]) {
   const int sd = a.p.scale_dim;
@@ -141,6 +147,10 @@ __device__ inline void scales_of(const SpawnArgs& a, int64_t g, int i, float s[3
 __global__ __launch_bounds__(256) void plan_kernel(SpawnArgs a, int64_t nk, int32_t* __restrict__ flag) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nk) return;
+  if (g >= (int64_t)rows_of(a) * a.p.k) {   // capacity rows behind the selected ones: never kept, never read
+    flag[g] = 0;
+    return;
+  }
   bool keep = true;
   if (a.p.alpha_filter_on) keep = tanhf(a.alpha_raw[g]) > 0.f;
   if (keep && a.p.scale_filter_on) {
@@ -155,11 +165,14 @@ __global__ __launch_bounds__(256) void plan_kernel(SpawnArgs a, int64_t nk, int3
 }
 
 __global__ void plan_finish_kernel(int64_t nk, const int32_t* __restrict__ flag, int32_t* __restrict__ dest,
-                                   int32_t* __restrict__ count) {
+                                   int32_t* __restrict__ count, int32_t* __restrict__ nan_flag) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nk) return;
   const int32_t f = flag[g], d = dest[g];  // dest holds the exclusive scan of flag
-  if (g == nk - 1) *count = d + f;
+  if (g == nk - 1) {
+    count[0] = d + f;
+    if (nan_flag) *nan_flag = 0;
+  }
   dest[g] = f ? d : -1;
 }
 
@@ -170,6 +183,8 @@ __global__ __launch_bounds__(256) void forward_kernel(SpawnArgs a, int64_t nk, f
                                                       uint8_t* __restrict__ o_free) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nk) return;
+  const int n_rows = rows_of(a);
+  if (g >= (int64_t)n_rows * a.p.k) return;
   const int i = (int)(g / a.p.k);
   const float alpha = tanhf(a.alpha_raw[g]);  // (:685)
   o_alpha_all[g] = alpha;                      // pre-filter clone (:721)
@@ -200,10 +215,13 @@ __global__ __launch_bounds__(256) void forward_kernel(SpawnArgs a, int64_t nk, f
     if (r1 != r1) r1 = 0.f;
     if (r2 != r2) r2 = 0.f;
     if (r3 != r3) r3 = 0.f;
-    o_rot[d * 4 + 0] = q.w * r0 - q.x * r1 - q.y * r2 - q.z * r3;
-    o_rot[d * 4 + 1] = q.w * r1 + q.x * r0 + q.y * r3 - q.z * r2;
-    o_rot[d * 4 + 2] = q.w * r2 - q.x * r3 + q.y * r0 + q.z * r1;
-    o_rot[d * 4 + 3] = q.w * r3 + q.x * r2 - q.y * r1 + q.z * r0;
+    const float o0 = q.w * r0 - q.x * r1 - q.y * r2 - q.z * r3, o1 = q.w * r1 + q.x * r0 + q.y * r3 - q.z * r2;
+    const float o2 = q.w * r2 - q.x * r3 + q.y * r0 + q.z * r1, o3 = q.w * r3 + q.x * r2 - q.y * r1 + q.z * r0;
+    o_rot[d * 4 + 0] = o0;
+    o_rot[d * 4 + 1] = o1;
+    o_rot[d * 4 + 2] = o2;
+    o_rot[d * 4 + 3] = o3;
+    if (a.nan_flag && (o0 != o0 || o1 != o1 || o2 != o2 || o3 != o3)) *a.nan_flag = 1;   // (:305-306) checked by render
   }
   // scale (:655-670)
   {
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256) void forward_kernel(SpawnArgs a, int64_t nk, f
     }
   }
   // the reference tiles the 1-D per-point mask ([n].repeat(1,k).view(-1), :724): Gaussian g gets free[g % n]
-  if (o_free && a.free_in) o_free[d] = a.free_in[g % a.p.n];
+  if (o_free && a.free_in) o_free[d] = a.free_in[g % n_rows];
 }
 
 __global__ __launch_bounds__(256) void backward_kernel(SpawnArgs a, int64_t nk, const float* __restrict__ g_xyz,
@@ -356,6 +374,17 @@ PINGS_API int pings_spawn_gather(int n, const int64_t* sel, const float* positio
                                  int view_concat, int dist_concat, float* pos, float* quat, float* base_color,
                                  uint8_t* free_out, float* geo_in, float* col_in, float* view_dist,
                                  void* stream) {
+  return pings_spawn_gather_dyn(n, nullptr, sel, position, orientation, color, free_mask, geo_feature, Fg, color_feature,
+                                Fc, cam_origin, xy_only, view_concat, dist_concat, pos, quat, base_color, free_out,
+                                geo_in, col_in, view_dist, stream);
+}
+
+PINGS_API int pings_spawn_gather_dyn(int n, const int32_t* n_rows_dev, const int64_t* sel, const float* position,
+                                     const float* orientation, const float* color, const uint8_t* free_mask,
+                                     const float* geo_feature, int Fg, const float* color_feature, int Fc,
+                                     const float* cam_origin, int xy_only, int view_concat, int dist_concat,
+                                     float* pos, float* quat, float* base_color, uint8_t* free_out, float* geo_in,
+                                     float* col_in, float* view_dist, void* stream) {
   PINGS_ARG_CHECK(n >= 0 && Fg > 0 && Fc > 0, "bad sizes");
   if (n == 0) return PINGS_OK;
   PINGS_ARG_CHECK(position && orientation && geo_feature && color_feature, "null map tensor");
@@ -371,7 +400,7 @@ PINGS_API int pings_spawn_gather(int n, const int64_t* sel, const float* positio
   a.sel = sel; a.position = position; a.orientation = orientation; a.color = color;
   a.geo_feature = geo_feature; a.color_feature = color_feature; a.cam = cam_origin; a.free_mask = free_mask;
   a.pos = pos; a.quat = quat; a.base = base_color; a.geo_in = geo_in; a.col_in = col_in;
-  a.view_dist = view_dist; a.free_out = free_out;
+  a.view_dist = view_dist; a.free_out = free_out; a.n_dev = n_rows_dev;
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope sc("spawn_gather", st);
   gather_kernel<<<grid_rows16(n), 256, 0, st>>>(a);
@@ -407,6 +436,12 @@ PINGS_API size_t pings_spawn_plan_scratch_bytes(int64_t num_gaussians) {
 PINGS_API int pings_spawn_plan(const pings_spawn_params* p, const float* alpha_raw, const float* scale_raw,
                                const float* dist_ratio, void* scratch, int32_t* dest, int32_t* count,
                                void* stream) {
+  return pings_spawn_plan_dyn(p, nullptr, alpha_raw, scale_raw, dist_ratio, scratch, dest, count, nullptr, stream);
+}
+
+PINGS_API int pings_spawn_plan_dyn(const pings_spawn_params* p, const int32_t* n_rows_dev, const float* alpha_raw,
+                                   const float* scale_raw, const float* dist_ratio, void* scratch, int32_t* dest,
+                                   int32_t* count, int32_t* nan_flag, void* stream) {
   if (int rc = check_params(p)) return rc;
   PINGS_ARG_CHECK(alpha_raw && dest && count && scratch, "null pointer");
   PINGS_ARG_CHECK(!p->scale_filter_on || scale_raw, "scale filter needs the scale MLP output");
@@ -414,11 +449,12 @@ PINGS_API int pings_spawn_plan(const pings_spawn_params* p, const float* alpha_r
   const int64_t nk = (int64_t)p->n * p->k;
   if (nk == 0) {
     PINGS_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    if (nan_flag) PINGS_HIP_CHECK(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), st));
     return PINGS_OK;
   }
   pings::prof::Scope sc("spawn_plan", st);
   SpawnArgs a{};
-  a.p = *p; a.alpha_raw = alpha_raw; a.scale_raw = scale_raw; a.dist_ratio = dist_ratio;
+  a.p = *p; a.alpha_raw = alpha_raw; a.scale_raw = scale_raw; a.dist_ratio = dist_ratio; a.n_dev = n_rows_dev;
   int32_t* flag = reinterpret_cast<int32_t*>(scratch);
   void* temp = reinterpret_cast<char*>(scratch) + (((size_t)nk * sizeof(int32_t) + 255) & ~(size_t)255);
   size_t tb = scan_temp_bytes(nk);
@@ -426,7 +462,7 @@ PINGS_API int pings_spawn_plan(const pings_spawn_params* p, const float* alpha_r
   plan_kernel<<<blocks, 256, 0, st>>>(a, nk, flag);
   PINGS_LAUNCH_CHECK();
   PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, dest, (int)nk, st));
-  plan_finish_kernel<<<blocks, 256, 0, st>>>(nk, flag, dest, count);
+  plan_finish_kernel<<<blocks, 256, 0, st>>>(nk, flag, dest, count, nan_flag);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
@@ -438,6 +474,19 @@ PINGS_API int pings_spawn_forward(const pings_spawn_params* p, const float* xyz_
                                   float* gaussian_xyz, float* gaussian_scale, float* gaussian_rot,
                                   float* gaussian_alpha, float* gaussian_color, float* alpha_all,
                                   uint8_t* gaussian_free_mask, void* stream) {
+  return pings_spawn_forward_dyn(p, nullptr, xyz_raw, rot_raw, scale_raw, alpha_raw, color_raw, pos, quat, base_color,
+                                 dist_ratio, free_in, dest, gaussian_xyz, gaussian_scale, gaussian_rot, gaussian_alpha,
+                                 gaussian_color, alpha_all, gaussian_free_mask, nullptr, stream);
+}
+
+PINGS_API int pings_spawn_forward_dyn(const pings_spawn_params* p, const int32_t* n_rows_dev, const float* xyz_raw,
+                                      const float* rot_raw, const float* scale_raw, const float* alpha_raw,
+                                      const float* color_raw, const float* pos, const float* quat,
+                                      const float* base_color, const float* dist_ratio, const uint8_t* free_in,
+                                      const int32_t* dest, float* gaussian_xyz, float* gaussian_scale,
+                                      float* gaussian_rot, float* gaussian_alpha, float* gaussian_color,
+                                      float* alpha_all, uint8_t* gaussian_free_mask, int32_t* nan_flag,
+                                      void* stream) {
   if (int rc = check_params(p)) return rc;
   const int64_t nk = (int64_t)p->n * p->k;
   if (nk == 0) return PINGS_OK;
@@ -448,7 +497,7 @@ PINGS_API int pings_spawn_forward(const pings_spawn_params* p, const float* xyz_
   SpawnArgs a{};
   a.p = *p; a.xyz_raw = xyz_raw; a.rot_raw = rot_raw; a.scale_raw = scale_raw; a.alpha_raw = alpha_raw;
   a.color_raw = color_raw; a.pos = pos; a.quat = quat; a.base = base_color; a.dist_ratio = dist_ratio;
-  a.free_in = free_in; a.dest = dest;
+  a.free_in = free_in; a.dest = dest; a.n_dev = n_rows_dev; a.nan_flag = nan_flag;
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope sc("spawn_forward", st);
   forward_kernel<<<(int)pings::ceil_div<int64_t>(nk, 256), 256, 0, st>>>(

@@ -69,7 +69,7 @@ def install(decoder_cls) -> None:
         decoder_cls.mlp_batch = lambda self, features: mlp_batch(self, features)
 
 
-def mlp_batch_group(decoders, features):
+def mlp_batch_group(decoders, features, fc=None):
     """`[d.mlp_batch(x) for d, x in zip(decoders, features)]` with ONE kernel launch each way when every decoder has
     the shape of the shipped spawn decoders (hidden 128, input <= 32; pings.py:156-160), else decoder by decoder."""
     if not features[0].is_cuda:
@@ -81,5 +81,7 @@ def mlp_batch_group(decoders, features):
         from . import mlp as _mlp
 
         params = [(d.layers[0].weight, d.layers[0].bias, d.lout.weight, d.lout.bias) for d in decoders]
-        return _mlp.fused_mlp_group(list(features), params)
+        return _mlp.fused_mlp_group(list(features), params, fc)
+    if fc is not None:
+        raise NotImplementedError("device-counted rows need the grouped MFMA decoders (hidden 128, input <= 32)")
     return [mlp_batch(d, x) for d, x in zip(decoders, features)]

@@ -66,14 +66,21 @@ class _Losses(torch.autograd.Function):
         ctx.prm, ctx.planes, ctx.sums = prm, planes, sums
         ctx.need = [t is not None and t.requires_grad for t in (rgb, depth, alpha, normal, dnormal)]
         ctx.mark_non_differentiable(sums)
-        return losses, sums
+        # the four means as outputs of their own (views of one buffer): indexing a [4] output afterwards would add a
+        # SelectBackward node (zeros + copy) per loss term to every backward pass
+        l0, l1, l2, l3 = losses.unbind(0)
+        return l0, l1, l2, l3, sums
 
     @staticmethod
-    def backward(ctx, g, _g_sums):
+    def backward(ctx, g0, g1, g2, g3, _g_sums):
         L = _lib.lib()
         rgb, gt_rgb, depth, gt_depth, alpha, normal, dnormal, sky = ctx.planes
         dev = rgb.device
-        gl = g.detach().to(torch.float32).contiguous()
+        gs = [g0, g1, g2, g3]
+        if any(g is None for g in gs):
+            zero = torch.zeros((), dtype=torch.float32, device=dev)
+            gs = [zero if g is None else g for g in gs]
+        gl = torch.stack(gs).to(torch.float32)
         like = lambda t, need: torch.empty_like(t) if (need and t is not None) else None
         outs = [like(t, n) for t, n in zip((rgb, depth, alpha, normal, dnormal), ctx.need)]
         st = L.pings_image_losses_backward(C.byref(ctx.prm), *[_lib.ptr(t) for t in ctx.planes], _lib.ptr(ctx.sums),
@@ -104,6 +111,6 @@ def image_losses(rendered_rgb: torch.Tensor, gt_rgb: torch.Tensor, rendered_dept
                        ("depth_normal", depth_normal, 3), ("sky_mask", sky_mask, 1)):
         if t is not None and (t.numel() != c * H * W or not t.is_cuda):
             raise ValueError(f"image_losses: {name} must be a HIP tensor of {c}x{H}x{W} elements, got {tuple(t.shape)}")
-    losses, sums = _Losses.apply(prm, rendered_rgb, gt_rgb, rendered_depth, gt_depth, rendered_alpha, rendered_normal,
-                                 depth_normal, sky_mask)
-    return ImageLosses(losses[0], losses[1], losses[2], losses[3], sums[1::2])
+    l0, l1, l2, l3, sums = _Losses.apply(prm, rendered_rgb, gt_rgb, rendered_depth, gt_depth, rendered_alpha,
+                                         rendered_normal, depth_normal, sky_mask)
+    return ImageLosses(l0, l1, l2, l3, sums[1::2])

@@ -26,10 +26,20 @@ class _Depth2Normal(torch.autograd.Function):
     def forward(ctx, depth, mask, weight, cx, cy, fx, fy):
         L = _lib.lib()
         _declare(L)
-        d = depth.detach().to(torch.float32).contiguous().clone()  # callers modify the depth map in place afterwards (:437)
+        # (round 2 cloned the depth here because `render` then normalised it in place, :430-437; it no longer does)
+        d = depth.detach()
+        if d.dtype != torch.float32 or not d.is_contiguous():
+            d = d.to(torch.float32).contiguous()
         _, H, W = d.shape
-        m = None if mask is None else mask.detach().to(torch.uint8).contiguous()
-        w = None if weight is None else weight.detach().to(torch.float32).contiguous()
+        m = None
+        if mask is not None:
+            m = mask.detach()
+            m = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
+        w = None
+        if weight is not None:
+            w = weight.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.to(torch.float32).contiguous()
         out = torch.empty(3, H, W, dtype=torch.float32, device=d.device)
         st = L.pings_depth2normal_forward(_lib.ptr(d), _lib.ptr(w), _lib.ptr(m), H, W, cx, cy, fx, fy, 0.0,
                                           _lib.ptr(out), _lib.stream_ptr(d.device))

@@ -31,6 +31,8 @@ def _declare(L):
     L.pings_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_mlp_forward_grouped.restype = C.c_int
     L.pings_mlp_forward_grouped.argtypes = [C.POINTER(_CJob), i32, i64, vp]
+    L.pings_mlp_forward_grouped_dyn.restype = C.c_int
+    L.pings_mlp_forward_grouped_dyn.argtypes = [C.POINTER(_CJob), i32, i64, vp, vp]
     L.pings_mlp_backward_grouped_scratch_bytes.restype = C.c_size_t
     L.pings_mlp_backward_grouped_scratch_bytes.argtypes = [C.POINTER(_CJob), i32]
     L.pings_mlp_backward_grouped.restype = C.c_int
@@ -115,7 +117,7 @@ class _FusedMLPGroup(torch.autograd.Function):
     fixed-order reduce).  Inputs: x_0 .. x_{J-1}, then W1, b1, W2, b2 of every job; outputs y_0 .. y_{J-1}."""
 
     @staticmethod
-    def forward(ctx, J, *args):
+    def forward(ctx, J, fc, *args):
         L = _lib.lib()
         _declare(L)
         f = lambda t: t.detach().to(torch.float32).contiguous()
@@ -131,8 +133,11 @@ class _FusedMLPGroup(torch.autograd.Function):
             ys.append(y)
             jobs[g] = _CJob(xs[g].data_ptr(), xs[g].shape[1], W2.shape[0], W1.data_ptr(), b1.data_ptr(), W2.data_ptr(),
                             b2.data_ptr(), y.data_ptr(), None, None, None, None, None, None)
-        _lib.check(L.pings_mlp_forward_grouped(jobs, J, N, _lib.stream_ptr(dev)), "pings_mlp_forward_grouped")
+        # fc (render_core.FrameCounts): N is the capacity, the rows to decode are counted on the device
+        _lib.check(L.pings_mlp_forward_grouped_dyn(jobs, J, N, fc.n_dev.data_ptr() if fc is not None else None,
+                                                   _lib.stream_ptr(dev)), "pings_mlp_forward_grouped")
         ctx.J = J
+        ctx.fc = fc
         ctx.need_x = [t.requires_grad for t in args[:J]]
         ctx.save_for_backward(*xs, *ps)
         return tuple(ys)
@@ -144,36 +149,60 @@ class _FusedMLPGroup(torch.autograd.Function):
         saved = ctx.saved_tensors
         xs, ps = saved[:J], saved[J:]
         N = xs[0].shape[0]
+        n_rows = ctx.fc.n_sel if ctx.fc is not None else N      # exact since the frame's read-back
         dev = xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         jobs = (_CJob * J)()
         gxs, gps, keep = [], [], []
+        # ONE buffer for the 4 J parameter gradients (views handed to autograd), one for the input gradients
+        sizes = []
+        for g in range(J):
+            IN, OUT = xs[g].shape[1], ps[4 * g + 2].shape[0]
+            sizes += [128 * IN, 128, OUT * 128, OUT]
+        flat = torch.empty(sum(sizes), **f32)
+        parts = flat.split(sizes)
+        base = flat.data_ptr()
+        in_cols = [xs[g].shape[1] if ctx.need_x[g] else 0 for g in range(J)]
+        gx_flat = torch.empty(N * sum(in_cols), **f32) if any(in_cols) else None
+        gx_off = 0
+        p_off = 0
         for g in range(J):
             W1, b1, W2, b2 = ps[4 * g:4 * g + 4]
             IN, OUT = xs[g].shape[1], W2.shape[0]
             gy = gys[g]
-            gy = torch.zeros(N, OUT, **f32) if gy is None else gy.detach().to(torch.float32).contiguous()
+            if gy is None:
+                gy = torch.zeros(N, OUT, **f32)
+            else:
+                gy = gy.detach()
+                if gy.dtype != torch.float32 or not gy.is_contiguous():
+                    gy = gy.to(torch.float32).contiguous()
             keep.append(gy)
-            gx = torch.empty(N, IN, **f32) if ctx.need_x[g] else None
-            flat = torch.empty(128 * IN + 128 + OUT * 128 + OUT, **f32)
-            gW1, gb1 = flat[:128 * IN].view(128, IN), flat[128 * IN:128 * IN + 128]
-            gW2, gb2 = flat[128 * IN + 128:128 * IN + 128 + OUT * 128].view(OUT, 128), flat[128 * IN + 128 + OUT * 128:]
+            gx = gx_ptr = None
+            if ctx.need_x[g]:
+                gx = gx_flat[gx_off:gx_off + N * IN].view(N, IN)
+                gx_ptr = gx_flat.data_ptr() + 4 * gx_off
+                gx_off += N * IN
+            s0, s1, s2, s3 = sizes[4 * g:4 * g + 4]
+            ptrs = (base + 4 * p_off, base + 4 * (p_off + s0), base + 4 * (p_off + s0 + s1),
+                    base + 4 * (p_off + s0 + s1 + s2))
+            p_off += s0 + s1 + s2 + s3
             gxs.append(gx)
-            gps += [gW1, gb1, gW2, gb2]
+            gps += [parts[4 * g].view(128, IN), parts[4 * g + 1], parts[4 * g + 2].view(OUT, 128), parts[4 * g + 3]]
             jobs[g] = _CJob(xs[g].data_ptr(), IN, OUT, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), None,
-                            gy.data_ptr(), gx.data_ptr() if gx is not None else None, gW1.data_ptr(), gb1.data_ptr(),
-                            gW2.data_ptr(), gb2.data_ptr())
+                            gy.data_ptr(), gx_ptr, *ptrs)
         scratch = torch.empty(L.pings_mlp_backward_grouped_scratch_bytes(jobs, J), dtype=torch.uint8, device=dev)
-        _lib.check(L.pings_mlp_backward_grouped(jobs, J, N, scratch.data_ptr(), _lib.stream_ptr(dev)),
+        _lib.check(L.pings_mlp_backward_grouped(jobs, J, n_rows, scratch.data_ptr(), _lib.stream_ptr(dev)),
                    "pings_mlp_backward_grouped")
-        return (None, *gxs, *gps)
+        return (None, None, *gxs, *gps)
 
 
-def fused_mlp_group(xs, params):
+def fused_mlp_group(xs, params, fc=None):
     """[y_j = relu(x_j W1_j^T + b1_j) W2_j^T + b2_j]: `xs` list of [N, IN_j], `params` list of (W1, b1, W2, b2)."""
     if not xs[0].is_cuda:
         raise _lib.PingsHipError("fused_mlp_group runs on the HIP device only (no CPU fallback)")
     if xs[0].shape[0] == 0 or not group_supported(xs, params):
+        if fc is not None:
+            raise NotImplementedError("device-counted rows need the grouped kernel")
         return [fused_mlp(x, *p) for x, p in zip(xs, params)]
     flat = [t for p in params for t in p]
-    return list(_FusedMLPGroup.apply(len(xs), *xs, *flat))
+    return list(_FusedMLPGroup.apply(len(xs), fc, *xs, *flat))

@@ -113,8 +113,8 @@ def _dx32(npm):
     """int32 copy of neighbor_dx on the device (cached on the object, rebuilt if it changes)."""
     dx = npm.neighbor_dx
     cache = getattr(npm, "_pings_dx32", None)
-    if cache is None or cache[0] is not dx:
-        cache = (dx, dx.to(torch.int32).contiguous())
+    if cache is None or cache[0] is not dx or cache[2] != dx._version:
+        cache = (dx, dx.to(torch.int32).contiguous(), dx._version)
         npm._pings_dx32 = cache
     return cache[1]
 
@@ -130,9 +130,9 @@ def _max_abs_dx(npm) -> int:
     """max |neighbor_dx| as a host value (one read-back per neighbourhood tensor, cached on the object)."""
     dx = npm.neighbor_dx
     cache = getattr(npm, "_pings_dxmax", None)
-    if cache is None or cache[0] is not dx:
+    if cache is None or cache[0] is not dx or cache[2] != dx._version:
         _lib.note_sync("knn_neighbourhood_extent")
-        cache = (dx, int(dx.abs().max().item()) if dx.numel() else 0)
+        cache = (dx, int(dx.abs().max().item()) if dx.numel() else 0, dx._version)
         npm._pings_dxmax = cache
     return cache[1]
 

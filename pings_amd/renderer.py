@@ -18,11 +18,18 @@ from typing import Dict
 
 import torch
 
+import os
+
 from . import _lib
 from . import decoder as _dec
 from . import image_ops as _img
 from . import rasterizer as _rast
+from . import render_core as _core
 from . import spawn as _spawn
+
+# PINGS_RENDER_SYNCS=legacy: round 2's path with three host synchronisations per frame (A/B runs; the tests compare
+# the two bit for bit).  Default: one synchronisation per frame (render_core.py).
+ONE_SYNC = os.environ.get("PINGS_RENDER_SYNCS", "one") != "legacy"
 
 
 # ------------------------------------------------------------------ depth -> normal (point_utils.py:83-149)
@@ -229,6 +236,15 @@ def render(viewpoint_camera,
         return None                     # :264-265
     visible = rasterizer.markVisible(neural_points_data["position"])
     n_all = visible.shape[0]
+    if ONE_SYNC and n_all >= 10 and _one_sync_supported(decoders, gs_type):
+        try:
+            return _render_one_sync(viewpoint_camera, rasterizer, neural_points_data, decoders, gaussians, visible,
+                                    dtype, device, img_scale, z_far, min_visible_neural_point_ratio, verbose,
+                                    replay_mode, dist_concat_on, view_concat_on, correct_exposure,
+                                    correct_exposure_affine, learn_color_residual, d2n_on, gs_type, min_alpha,
+                                    displacement_range_ratio, max_scale_ratio, unit_scale_ratio)
+        except _core.LegacyFrame:
+            pass                        # fewer than 10 selected neural points (:572): the path below handles it
     # ONE read-back for both counts the control flow needs: visible points (reference: `.item()` at :219) and rows
     # of the spawn mask (reference: boolean-mask indexing at :563-569, a second synchronisation there)
     valid = neural_points_data.get("valid_mask", None)
@@ -277,15 +293,22 @@ def render(viewpoint_camera,
         screenspace_points.retain_grad()
     except Exception:
         pass
-    # reference: `assert not torch.isnan(rotations).any()` (:305-306) right here, a synchronisation of its own.  The
-    # flag is computed here and READ after the rasteriser call, whose instance-count read-back has drained the stream
-    # anyway (a NaN quaternion is culled by the kernels: non-finite radius), so the assert costs no extra wait.
+    # reference: `assert not torch.isnan(rotations).any()` (:305-306) right here, a synchronisation of its own (the
+    # one-synchronisation path folds the flag into the rasteriser's read-back; here it is a wait for the blend kernels)
     nan_flag = torch.isnan(rotations).any()
 
     out = rasterizer(means3D=means3D, means2D=screenspace_points, colors_precomp=colors, opacities=opacity,
                      scales=scales, rotations=rotations, theta=viewpoint_camera.cam_rot_delta,
                      rho=viewpoint_camera.cam_trans_delta)
+    _lib.note_sync("nan_rotation_assert")
     assert not bool(nan_flag), "NaN in rotation"
+    return _finish(results, out, screenspace_points, viewpoint_camera, gs_type, d2n_on, img_scale, min_alpha,
+                   correct_exposure, correct_exposure_affine)
+
+
+def _finish(results, out, screenspace_points, viewpoint_camera, gs_type, d2n_on, img_scale, min_alpha,
+            correct_exposure, correct_exposure_affine):
+    """Image-space tail of `render` (:318-466), shared by both paths."""
     if gs_type == "gaussian_surfel":
         rendered_image, rendered_normal, rendered_depth, rendered_alpha, radii, contributions = out
         alpha_detached = rendered_alpha.detach()
@@ -300,11 +323,14 @@ def render(viewpoint_camera,
         rendered_image, radii, rendered_depth, rendered_alpha, n_touched = out
         alpha_detached = rendered_alpha.detach()
         mask_vis = alpha_detached > min_alpha
-        rendered_depth[mask_vis] /= alpha_detached[mask_vis]               # in place, like :430
+        # :430-437 normalise the depth in place through boolean-mask indexing (two more host synchronisations:
+        # `nonzero`); the same values and gradients without leaving the stream: d2n sees depth / alpha where the mask
+        # holds and the raw depth elsewhere, the returned map is zero outside the mask
+        norm_depth = torch.where(mask_vis, rendered_depth / alpha_detached.clamp_min(1e-30), rendered_depth)
         d2n = None
         if d2n_on:
-            d2n = depth2normal(rendered_depth, mask_vis, viewpoint_camera, img_scale=img_scale, weight=alpha_detached)
-        rendered_depth[~mask_vis] = 0.0
+            d2n = depth2normal(norm_depth, mask_vis, viewpoint_camera, img_scale=img_scale, weight=alpha_detached)
+        rendered_depth = torch.where(mask_vis, norm_depth, torch.zeros_like(norm_depth))
         results.update({"rend_normal": None, "surf_depth": rendered_depth, "rend_alpha": rendered_alpha,
                         "surf_normal": d2n, "rend_dist": None, "viewspace_points": screenspace_points,
                         "visibility_filter": radii > 0, "radii": radii})
@@ -319,3 +345,90 @@ def render(viewpoint_camera,
             rendered_image = torch.exp(viewpoint_camera.exposure_a) * rendered_image + viewpoint_camera.exposure_b
     results.update({"render": rendered_image})
     return results
+
+
+# ------------------------------------------------------------------ one synchronisation per frame
+def _one_sync_supported(decoders, gs_type) -> bool:
+    names = ("gauss_xyz", "gauss_rot", "gauss_scale", "gauss_alpha", "gauss_color")
+    if not all(n in decoders for n in names):
+        return False
+    ds = [decoders[n] for n in names]
+    if not all(_dec._supported(d) for d in ds):
+        return False
+    k = ds[0].out_k
+    sd = int(decoders["gauss_scale"].lout.weight.shape[0]) // k
+    if gs_type != "gaussian_surfel" and sd != 3:
+        return False
+    from . import mlp as _mlp
+
+    # the grouped MFMA kernels (hidden 128, input <= 32 + view features) are the only decoders that read a device count
+    return all(d.layers[0].weight.shape[0] == 128 and d.layers[0].weight.shape[1] <= 32 and d.lout.weight.shape[0] <= 32
+               for d in ds)
+
+
+def _render_one_sync(cam, rasterizer, d, decoders, gaussians, visible, dtype, device, img_scale, z_far, min_ratio,
+                     verbose, replay_mode, dist_concat_on, view_concat_on, correct_exposure, correct_exposure_affine,
+                     learn_color_residual, d2n_on, gs_type, min_alpha, displacement_range_ratio, max_scale_ratio,
+                     unit_scale_ratio):
+    """`render` from `markVisible` on with every count left on the device until the rasteriser's read-back
+    (render_core.py).  Same results as the legacy path bit for bit (tests/test_render.py)."""
+    pos_all, quat_all = d["position"], d["orientation"]
+    n_all = int(visible.shape[0])
+    valid = d.get("valid_mask", None)
+    mask = visible & valid if valid is not None else visible
+    counts = torch.stack((visible.sum(dtype=torch.int32), mask.sum(dtype=torch.int32)))
+    sel = torch.nonzero_static(mask, size=n_all, fill_value=0).view(-1)      # capacity-sized; rows behind the count unused
+    fc = _core.FrameCounts(n_all, counts[0:1], counts[1:2])
+    m_xyz, m_scale, m_rot = decoders["gauss_xyz"], decoders["gauss_scale"], decoders["gauss_rot"]
+    m_alpha, m_color = decoders["gauss_alpha"], decoders["gauss_color"]
+    k = m_xyz.out_k
+    res = float(d["resolution"])
+    geo_feat, col_feat = d["geo_feature"], d["color_feature"]
+    cam_origin = cam.camera_center
+    geo_in, col_in, pos, quat, base, free, view_dist = _spawn.gather(
+        geo_feat, col_feat, sel, pos_all, quat_all, d.get("color", None), d.get("free_mask", None), cam_origin, True,
+        view_concat_on, dist_concat_on, fc)
+    geo_plain = geo_in[:, :geo_feat.shape[1]] if geo_in.shape[1] != geo_feat.shape[1] else geo_in
+    raws = _dec.mlp_batch_group([m_xyz, m_rot, m_scale, m_alpha, m_color],
+                                [geo_plain, geo_plain, geo_plain, geo_in, col_in], fc)
+    st = _core._State()
+    st.prep, st.fc = rasterizer._prepared(), fc
+    sd = int(raws[2].shape[1] // k)
+    st.prm = dict(n=n_all, k=int(k), scale_dim=sd, surfel=int(gs_type == "gaussian_surfel"),
+                  color_residual=int(bool(learn_color_residual and base is not None)), alpha_filter_on=1,
+                  scale_filter_on=0, displacement_range=float(displacement_range_ratio * res),
+                  unit_scale=float(unit_scale_ratio * res), max_scale=float(max_scale_ratio * res),
+                  scale_filter_thr=float(0.2 * res))
+    st.pos, st.quat = pos, quat
+    st.base = base if learn_color_residual else None
+    st.dist_ratio = None                 # render() never passes dist_adaptive_scale (:236-262)
+    st.free = free
+    st.min_ratio, st.replay_mode, st.n_all = float(min_ratio), bool(replay_mode), n_all
+    frozen = None
+    st.frozen_nan = None
+    if gaussians is not None and gaussians["gaussian_xyz"].shape[0] > 10:    # frozen surrounding map (:267-281)
+        frozen = (gaussians["gaussian_xyz"], gaussians["gaussian_alpha"], gaussians["gaussian_scale"],
+                  gaussians["gaussian_rot"], gaussians["gaussian_color"])
+        st.frozen_nan = torch.isnan(frozen[3]).any().to(torch.int32).reshape(1)
+    st.viewspace = None
+    try:
+        out = _core.spawn_and_rasterise(raws, cam.cam_rot_delta, cam.cam_trans_delta, frozen, st)
+    except _core.SkipFrame as e:
+        if verbose:
+            print("[Render] {}, skip this frame {}".format(e, cam.uid))
+        return None
+    (o_color, o_normal, o_depth, o_alpha, radii, per_g, xyz, scale, rot, alpha, color, alpha_all, gfree) = out
+    M = frozen[0].shape[0] if frozen is not None else 0
+    screenspace_points = torch.zeros(fc.count + M, 3, requires_grad=True, dtype=dtype, device=device)
+    st.viewspace = screenspace_points   # receives d L / d means2D in the backward pass (the reference never reads it)
+    results = {"gaussian_xyz": xyz, "gaussian_scale": scale, "gaussian_rot": rot, "gaussian_alpha": alpha,
+               "gaussian_color": color, "alpha_all": alpha_all,
+               "gaussian_free_mask": None if gfree is None else gfree.bool(),
+               "local_view_gaussian_count": fc.count, "shifted_position": None,
+               "visible_neural_point_ratio": 1.0 * fc.n_vis / n_all}
+    if gs_type == "gaussian_surfel":
+        raster_out = (o_color, o_normal, o_depth, o_alpha, radii, per_g)
+    else:
+        raster_out = (o_color, radii, o_depth, o_alpha, per_g)
+    return _finish(results, raster_out, screenspace_points, cam, gs_type, d2n_on, img_scale, min_alpha,
+                   correct_exposure, correct_exposure_affine)

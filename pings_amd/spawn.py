@@ -32,6 +32,9 @@ def _declare(L):
     L.pings_spawn_gather.restype = C.c_int
     L.pings_spawn_gather.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32,
                                      vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pings_spawn_gather_dyn.restype = C.c_int
+    L.pings_spawn_gather_dyn.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32,
+                                         vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_spawn_gather_backward.restype = C.c_int
     L.pings_spawn_gather_backward.argtypes = [i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp]
     L.pings_spawn_plan_scratch_bytes.restype = C.c_size_t
@@ -58,7 +61,7 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 class _Gather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, geo_feature, color_feature, sel, position, orientation, color, free_mask, cam_origin,
-                xy_only, view_concat, dist_concat):
+                xy_only, view_concat, dist_concat, fc=None):
         L = _lib_ready()
         dev = geo_feature.device
         gf, cf = _f32c(geo_feature), _f32c(color_feature)
@@ -78,13 +81,16 @@ class _Gather(torch.autograd.Function):
         col_in = torch.empty(n, Fc + 3 * int(view_concat), **f32)
         vdist = torch.empty(n, 1, **f32) if cam is not None else None
         selc = None if sel is None else sel.to(torch.int64).contiguous()
-        st = L.pings_spawn_gather(n, _lib.ptr(selc), _lib.ptr(pos_all), _lib.ptr(quat_all), _lib.ptr(col_all),
-                                  _lib.ptr(free_all), _lib.ptr(gf), Fg, _lib.ptr(cf), Fc, _lib.ptr(cam),
-                                  int(bool(xy_only)), int(view_concat), int(dist_concat), _lib.ptr(pos),
-                                  _lib.ptr(quat), _lib.ptr(base), _lib.ptr(free), _lib.ptr(geo_in), _lib.ptr(col_in),
-                                  _lib.ptr(vdist), _lib.stream_ptr(dev))
+        # fc (render_core.FrameCounts): `sel` is capacity-sized and the selected-row count is a device word
+        st = L.pings_spawn_gather_dyn(n, fc.n_dev.data_ptr() if fc is not None else None, _lib.ptr(selc),
+                                      _lib.ptr(pos_all), _lib.ptr(quat_all), _lib.ptr(col_all),
+                                      _lib.ptr(free_all), _lib.ptr(gf), Fg, _lib.ptr(cf), Fc, _lib.ptr(cam),
+                                      int(bool(xy_only)), int(view_concat), int(dist_concat), _lib.ptr(pos),
+                                      _lib.ptr(quat), _lib.ptr(base), _lib.ptr(free), _lib.ptr(geo_in), _lib.ptr(col_in),
+                                      _lib.ptr(vdist), _lib.stream_ptr(dev))
         _lib.check(st, "pings_spawn_gather")
         ctx.sel = selc
+        ctx.fc = fc
         ctx.shapes = (tuple(geo_feature.shape), tuple(color_feature.shape), n, Fg, Fc, geo_in.shape[1], col_in.shape[1])
         outs = (geo_in, col_in, pos, quat, base, free, vdist)
         ctx.mark_non_differentiable(*[o for o in outs[2:] if o is not None])
@@ -94,6 +100,8 @@ class _Gather(torch.autograd.Function):
     def backward(ctx, g_geo_in, g_col_in, *_):
         L = _lib_ready()
         gshape, cshape, n, Fg, Fc, ldg, ldc = ctx.shapes
+        if ctx.fc is not None:
+            n = ctx.fc.n_sel                    # the exact row count, known since the frame's read-back
         dev = (g_geo_in if g_geo_in is not None else g_col_in).device
         d_geo = d_col = None
         gg = gc = None
@@ -106,16 +114,16 @@ class _Gather(torch.autograd.Function):
         st = L.pings_spawn_gather_backward(n, _lib.ptr(ctx.sel), _lib.ptr(gg), Fg, ldg, _lib.ptr(gc), Fc, ldc,
                                            _lib.ptr(d_geo), _lib.ptr(d_col), _lib.stream_ptr(dev))
         _lib.check(st, "pings_spawn_gather_backward")
-        return (d_geo, d_col) + (None,) * 9
+        return (d_geo, d_col) + (None,) * 10
 
 
 def gather(geo_feature, color_feature, sel, position, orientation, color, free_mask, cam_origin, xy_only,
-           view_concat, dist_concat):
+           view_concat, dist_concat, fc=None):
     """-> geo_in, col_in, pos, quat, base_color, free (uint8), view_dist[n,1] (None without cam_origin)."""
     if not geo_feature.is_cuda:
         raise _lib.PingsHipError("spawn_gaussians runs on the HIP device only (no CPU fallback)")
     return _Gather.apply(geo_feature, color_feature, sel, position, orientation, color, free_mask, cam_origin,
-                         xy_only, view_concat, dist_concat)
+                         xy_only, view_concat, dist_concat, fc)
 
 
 @dataclass
