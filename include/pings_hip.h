@@ -290,6 +290,12 @@ PINGS_API int pings_query_feature_forward(const pings_knn_map* m, const pings_qf
                                           int64_t* idx_out, int64_t* gidx_out, int64_t* nn_counts,
                                           float* certainty, float* certainty_accum, const int32_t* query_ts,
                                           int32_t* ts_update, float* n_out, void* stream);
+/* certainties[idx[p]] += w[p] for the n_pairs = B * nn_k pairs a forward call returned (idx < 0 skipped): the training-
+ * mode accumulation of :664-689 as its own O(B nn_k) launch behind the forward kernel (stream order guarantees that the
+ * queried certainty, :691-695, was computed from the values before the accumulation).  Float atomics, as the
+ * reference's scatter_add_. */
+PINGS_API int pings_query_feature_accumulate(const int64_t* idx, const float* w, int64_t n_pairs, float* certainties,
+                                             void* stream);
 /* n_out [B, nn_k, 3] (optional): the neighbour vectors on their own (they are also columns F..F+2 of the rows). */
 
 /* Backward: upstream g_geo / g_color (shapes of the forward outputs, NULL = none) and g_w [B, nn_k] ->
@@ -450,6 +456,20 @@ PINGS_API int pings_exposure_forward(const float* img, const float* M, const flo
 PINGS_API size_t pings_exposure_backward_scratch_bytes(void);
 PINGS_API int pings_exposure_backward(const float* img, const float* M, const float* g_out, int64_t HW,
                                       void* scratch, float* g_img, float* g_M, float* g_b, void* stream);
+
+/* ------------------------------------------ finite-difference SDF gradient
+ * The tensor code of `Mapper.get_numerical_gradient` (utils/mapper.py:2319-2370) around the fused SDF query:
+ *   pings_stencil_points            x[N,3] -> [x+ex; x-ex; x+ey; x-ey; x+ez; x-ez] ([6N,3]; one-sided: 3 blocks, [3N,3])
+ *   pings_sdf_forward / _backward   on the shifted points (above)
+ *   pings_stencil_gradient          S[6N] -> grad[N,3] = (S+ - S-) / (2 eps)   (one-sided: (S+ - sdf_x) / eps)
+ *   pings_stencil_gradient_backward dL/dgrad[N,3] -> dL/dS[6N] (one-sided also dL/dsdf_x[N], nullable)
+ * Divisions are multiplications by the fp32 reciprocal of the fp32 divisor, as torch's device kernel for
+ * tensor / python-float computes them. */
+PINGS_API int pings_stencil_points(const float* x, int64_t N, float eps, int two_side, float* out, void* stream);
+PINGS_API int pings_stencil_gradient(const float* sdf_shifted, const float* sdf_x, int64_t N, float eps, int two_side,
+                                     float* grad, void* stream);
+PINGS_API int pings_stencil_gradient_backward(const float* dL_dgrad, int64_t N, float eps, int two_side,
+                                              float* dL_dsdf_shifted, float* dL_dsdf_x, void* stream);
 
 /* ------------------------------------------------------- spawn_gaussians
  * Replaces the tensor code of `spawn_gaussians` around the five decoder MLPs

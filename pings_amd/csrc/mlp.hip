@@ -291,6 +291,73 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_wave_grouped_kernel(long long 
   mlp_fwd_wave_body(N, j.IN[g], j.OUT[g], j.x[g], j.W1[g], j.b1[g], j.W2[g], j.b2[g], j.y[g]);
 }
 
+// ---------------------------------------------------------------- forward, SDF decoder shape (HID 64, OUT 1)
+// `Decoder.sdf` (model/decoder.py:100-104) on [N, F + 3] rows: the general kernels above pad OUT = 1 to a 32-wide
+// second product (96 % of its MFMAs multiply zeros) and stage the tile through LDS with three barriers.  Here a wave
+// owns a 32-row tile outright, no LDS, no barrier:
+//   H^T[64 x 32] = [W1 | b1] [x | 1]^T   two 32x32 accumulators (hidden blocks), KS k-steps of v_mfma_f32_32x32x2_f32;
+//                                        the k order is free, so lane half h takes input columns KS*h .. KS*h + KS - 1:
+//                                        KS consecutive floats of the lane's own row (loaded straight into the B
+//                                        operand, the next tile's row in flight meanwhile), W1 columns in the same
+//                                        order as register-resident A fragments; column IN is the bias (x = 1);
+//   y[row] = b2 + sum_h W2[h] relu(H^T[h][row])   on the accumulator layout (column = row of the tile on the lane,
+//                                        16 hidden units per register set and lane half): 32 fma + one half swap.
+// 2 * KS MFMAs per 32 rows (36 for F = 32) against 18 + 16 + 16 * 2 of the padded product.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_h64o1_kernel(long long N, int IN, const float* __restrict__ x,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1,
+                                                               const float* __restrict__ W2, const float* __restrict__ b2,
+                                                               float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  float w1f[2][KS], w2f[2][16];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    const int hid = hb * 32 + r;                     // A operand: row m = r, k = half
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int c = KS * h + s2;
+      w1f[hb][s2] = c < IN ? W1[(size_t)hid * IN + c] : (c == IN ? b1[hid] : 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w2f[hb][q] = W2[hb * 32 + rowmap(q, h)];
+  }
+  const float bias2 = b2[0];
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  float xf[KS], xn[KS];
+  auto fetch = [&](long long t, float (&dst)[KS]) {
+    const long long row = t * 32 + r;
+    const bool ok = row < N;
+    const float* src = x + (size_t)(ok ? row : 0) * IN;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int c = KS * h + s2;
+      dst[s2] = c < IN ? (ok ? src[c] : 0.f) : (c == IN ? 1.f : 0.f);
+    }
+  };
+  if (wave0 < ntiles) fetch(wave0, xn);
+  for (long long t = wave0; t < ntiles; t += nwaves) {
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) xf[s2] = xn[s2];
+    if (t + nwaves < ntiles) fetch(t + nwaves, xn);
+    f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {               // two independent accumulator chains, interleaved
+      a0 = mfma(w1f[0][s2], xf[s2], a0);
+      a1 = mfma(w1f[1][s2], xf[s2], a1);
+    }
+    float p = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) p = fmaf(w2f[0][q], fmaxf(a0[q], 0.f), p);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) p = fmaf(w2f[1][q], fmaxf(a1[q], 0.f), p);
+    p += __shfl_xor(p, 32, 64);                     // the other 32 hidden units of this row
+    const long long row = t * 32 + r;
+    if (h == 0 && row < N) y[row] = p + bias2;
+  }
+}
+
 // ---------------------------------------------------------------- backward
 // scratch layout per workgroup: [HID*IN] gW1, [OUT*HID] gW2, [HID] gb1, [OUT] gb2
 __host__ __device__ inline size_t partial_floats(int IN, int HID, int OUT) {
@@ -963,6 +1030,20 @@ PINGS_API int pings_mlp_forward(const float* x, int64_t N, int IN, int HID, int 
     const long long want = (ntiles + 3) / 4;
     const unsigned grid_w = (unsigned)(want < 512 ? want : 512);
     hipLaunchKernelGGL(mlp_fwd_wave_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, IN, OUT, x, W1, b1, W2, b2, y);
+    PINGS_LAUNCH_CHECK();
+    return PINGS_OK;
+  }
+  if (HID == 64 && OUT == 1 && IN <= 35 && getenv("PINGS_MLP_FWD_WG") == nullptr) {
+    // the SDF decoder (Decoder.sdf): column-per-lane kernel, two workgroups of four waves per CU
+    pings::prof::Scope ps("mlp_fwd", st);
+    const long long want = (ntiles + 3) / 4;
+    const unsigned grid_w = (unsigned)(want < 512 ? want : 512);
+#define PINGS_MLP_H64O1(KS_)                                                                                       \
+  hipLaunchKernelGGL(mlp_fwd_h64o1_kernel<KS_>, dim3(grid_w), dim3(256), 0, st, (long long)N, IN, x, W1, b1, W2, b2, y)
+    if (IN + 1 <= 12) PINGS_MLP_H64O1(6);
+    else if (IN + 1 <= 20) PINGS_MLP_H64O1(10);
+    else PINGS_MLP_H64O1(18);
+#undef PINGS_MLP_H64O1
     PINGS_LAUNCH_CHECK();
     return PINGS_OK;
   }

@@ -419,6 +419,32 @@ PINGS_API int pings_query_feature_forward(const pings_knn_map* m, const pings_qf
   return PINGS_OK;
 }
 
+namespace {
+// certainty[row] += w for every (query, neighbour) pair of a batch (:664-689), launched BEHIND the forward kernel: every
+// read of the queried certainty (:691-695) has completed by then, so the table itself can be the target and the work
+// is O(B nn_k) as the reference's scatter_add_, not O(rows) (round 2: a zeroed table-sized delta + one full-table add)
+__global__ __launch_bounds__(256) void qf_accumulate_kernel(const long long* __restrict__ idx, const float* __restrict__ w,
+                                                            long long n_pairs, float* __restrict__ cert) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const long long id = idx[p];
+  if (id >= 0) atomicAdd(&cert[id], w[p]);
+}
+}  // namespace
+
+PINGS_API int pings_query_feature_accumulate(const int64_t* idx, const float* w, int64_t n_pairs, float* certainties,
+                                             void* stream) {
+  PINGS_ARG_CHECK(n_pairs >= 0, "negative pair count");
+  if (n_pairs == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(idx && w && certainties, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope ps("qf_accumulate", st);
+  hipLaunchKernelGGL(qf_accumulate_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st,
+                     (const long long*)idx, w, (long long)n_pairs, certainties);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
 PINGS_API size_t pings_query_feature_scratch_bytes(int64_t B, int nn_k, int64_t rows) {
   if (nn_k <= 0 || rows <= 0) return 0;
   return carve_qf(nullptr, B, nn_k, rows).total;

@@ -68,6 +68,9 @@ def get_numerical_gradient(self, x, sdf_x=None, eps=0.02, two_side=True):
     """utils/mapper.py:2319-2370: finite-difference SDF gradient; the 6 N (or 3 N) shifted queries go through ONE
     fused forward launch (and one fused backward when the loss is differentiated)."""
     N = x.shape[0]
+    if x.is_cuda and N > 0 and not (torch.is_grad_enabled() and x.requires_grad) and (two_side or sdf_x is not None):
+        # one graph node: shifted points -> fused query -> differences (pings_amd.neural_points._NumGrad)
+        return _np.numerical_gradient(self.neural_points, self.sdf_mlp, x, sdf_x, eps, two_side)
     e = torch.eye(3, dtype=x.dtype, device=x.device) * eps
     if two_side:
         xs = torch.cat((x + e[0], x - e[0], x + e[1], x - e[1], x + e[2], x - e[2]), dim=0)

@@ -57,6 +57,8 @@ def _declare(L):
     vp = C.c_void_p
     L.pings_query_feature_forward.restype = C.c_int
     L.pings_query_feature_forward.argtypes = [C.POINTER(_CKnnMap), C.POINTER(_CQfTables), vp, C.c_int64] + [vp] * 12
+    L.pings_query_feature_accumulate.restype = C.c_int
+    L.pings_query_feature_accumulate.argtypes = [vp, vp, C.c_int64, vp, vp]
     L.pings_query_feature_scratch_bytes.restype = C.c_size_t
     L.pings_query_feature_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int64]
     L.pings_query_feature_backward.restype = C.c_int
@@ -396,11 +398,9 @@ def _qf_forward(x, geo_tab, col_tab, npm, opts, want_n: bool):
     gidx = torch.empty(B, nn_k, dtype=torch.int64, device=dev)
     cnt = torch.empty(B, dtype=torch.int64, device=dev)
     cert = torch.empty(B, **f32) if cert_tab is not None else None
-    acc = ts_tab = qts = None
-    if accumulate_stability and cert_tab is not None:       # :664-689, under no_grad in the reference
-        # the queried certainty (:691-695) is computed from the values gathered BEFORE the accumulation (:615-620), so
-        # the kernel adds into a zeroed delta while every wave reads the untouched table; one add folds it in afterwards
-        acc = torch.zeros_like(cert_tab)
+    ts_tab = qts = None
+    accumulate = bool(accumulate_stability and cert_tab is not None)       # :664-689, under no_grad in the reference
+    if accumulate:
         if query_locally and query_ts is not None:
             ts_tab = npm.local_point_ts_update
             if ts_tab.dtype != torch.int32 or not ts_tab.is_contiguous():
@@ -408,11 +408,13 @@ def _qf_forward(x, geo_tab, col_tab, npm, opts, want_n: bool):
             qts = query_ts.detach().to(torch.int32).contiguous()
     _lib.check(L.pings_query_feature_forward(
         C.byref(a.c), C.byref(tabs), _lib.ptr(q), B, _lib.ptr(geo), _lib.ptr(col), _lib.ptr(w), _lib.ptr(idx),
-        _lib.ptr(gidx), _lib.ptr(cnt), _lib.ptr(cert), _lib.ptr(acc), _lib.ptr(qts), _lib.ptr(ts_tab), _lib.ptr(n),
+        _lib.ptr(gidx), _lib.ptr(cnt), _lib.ptr(cert), None, _lib.ptr(qts), _lib.ptr(ts_tab), _lib.ptr(n),
         _lib.stream_ptr(dev)), "pings_query_feature_forward")
-    if acc is not None:
-        with torch.no_grad():
-            cert_tab.add_(acc)
+    if accumulate and B > 0:
+        # the queried certainty (:691-695) is computed from the values gathered BEFORE the accumulation (:615-620): the
+        # increments go in as a second O(B k) launch behind the forward kernel, straight into the table
+        _lib.check(L.pings_query_feature_accumulate(idx.data_ptr(), w.data_ptr(), B * nn_k, cert_tab.data_ptr(),
+                                                    _lib.stream_ptr(dev)), "pings_query_feature_accumulate")
     st.idx, st.gidx = idx, gidx
     st.geo_buf, st.col_buf = geo, col
     st.keep = a      # the map tensors the C struct points at
@@ -845,40 +847,53 @@ class _SdfTrainBackward(torch.autograd.Function):
         return d_g, None, dF, dW1, db1, dW2, db2, None
 
 
+def _c(t):
+    t = t.detach()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _sdf_train_forward(x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, query_locally, use_meas, use_valid,
+                       need_gx):
+    """`pings_sdf_forward` with the neighbour lists kept: (sdf [B], nn_counts [B], state for `_sdf_first_order`)."""
+    L = _L()
+    q = x.detach()
+    if q.dtype != torch.float32 or not q.is_contiguous():
+        q = q.to(torch.float32).contiguous()
+    B = q.shape[0]
+    a = _map_args(npm, bool(npm.temporal_local_map_on and query_locally), use_meas, use_valid, query_locally)
+    f, W1c, b1c, W2c, b2c = _c(feats), _c(W1), _c(b1), _c(W2), _c(b2)
+    F = f.shape[1]
+    dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(W1c.shape[0]), int(F),
+                    float(sdf_scale), int(weighted_first))
+    pts = _c(npm.local_neural_points if query_locally else npm.neural_points)
+    quat = _c(npm.local_point_orientations if query_locally else npm.point_orientations)
+    gpts = _c(npm.neural_points)
+    dev = q.device
+    nn_k = a.nn_k
+    sdf = torch.empty(B, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int64, device=dev)
+    idx = torch.empty(B, nn_k, dtype=torch.int64, device=dev)
+    w = torch.empty(B, nn_k, dtype=torch.float32, device=dev)
+    gidx = torch.empty(B, nn_k, dtype=torch.int64, device=dev) if need_gx else None
+    unit = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
+    st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), f.data_ptr(), pts.data_ptr(), quat.data_ptr(), None,
+                             int(bool(npm.after_pgo)), q.data_ptr(), B, sdf.data_ptr(), _lib.ptr(unit), cnt.data_ptr(),
+                             None, idx.data_ptr(), w.data_ptr(), None, _lib.ptr(gidx), _lib.stream_ptr(dev))
+    _lib.check(st, "pings_sdf_forward")
+    state = {"saved": (q, f, W1c, b1c, W2c, b2c, idx, gidx, w, pts, quat, gpts, unit),
+             "meta": (float(sdf_scale), int(weighted_first), bool(npm.after_pgo), nn_k),
+             "need_params": any(t.requires_grad for t in (feats, W1, b1, W2, b2)), "keep": a}
+    return sdf, cnt, state
+
+
 class _SdfTrain(torch.autograd.Function):
     """S(x) with fused first- and second-order backward to the feature table and the decoder
     (`pings_sdf_forward` / `pings_sdf_backward` / `pings_sdf_double_backward`)."""
 
     @staticmethod
     def forward(ctx, x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, query_locally, use_meas, use_valid):
-        L = _L()
-        q = x.detach().to(torch.float32).contiguous()
-        B = q.shape[0]
-        a = _map_args(npm, bool(npm.temporal_local_map_on and query_locally), use_meas, use_valid, query_locally)
-        f = feats.detach().contiguous()
-        W1c, b1c = W1.detach().contiguous(), b1.detach().contiguous()
-        W2c, b2c = W2.detach().contiguous(), b2.detach().contiguous()
-        F = f.shape[1]
-        dec = _CDecoder(W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(), int(W1c.shape[0]), int(F),
-                        float(sdf_scale), int(weighted_first))
-        pts = (npm.local_neural_points if query_locally else npm.neural_points).detach().contiguous()
-        quat = (npm.local_point_orientations if query_locally else npm.point_orientations).detach().contiguous()
-        gpts = npm.neural_points.detach().contiguous()
-        dev = q.device
-        sdf = torch.empty(B, dtype=torch.float32, device=dev)
-        cnt = torch.empty(B, dtype=torch.int64, device=dev)
-        idx = torch.empty(B, a.nn_k, dtype=torch.int64, device=dev)
-        w = torch.empty(B, a.nn_k, dtype=torch.float32, device=dev)
-        need_gx = x.requires_grad
-        gidx = torch.empty(B, a.nn_k, dtype=torch.int64, device=dev) if need_gx else None
-        unit = torch.empty(B, 3, dtype=torch.float32, device=dev) if need_gx else None
-        st = L.pings_sdf_forward(C.byref(a.c), C.byref(dec), _lib.ptr(f), _lib.ptr(pts), _lib.ptr(quat), None,
-                                 int(bool(npm.after_pgo)), _lib.ptr(q), B, _lib.ptr(sdf), _lib.ptr(unit), _lib.ptr(cnt),
-                                 None, _lib.ptr(idx), _lib.ptr(w), None, _lib.ptr(gidx), _lib.stream_ptr(dev))
-        _lib.check(st, "pings_sdf_forward")
-        ctx.state = {"saved": (q, f, W1c, b1c, W2c, b2c, idx, gidx, w, pts, quat, gpts, unit),
-                     "meta": (float(sdf_scale), int(weighted_first), bool(npm.after_pgo), a.nn_k),
-                     "need_params": any(t.requires_grad for t in (feats, W1, b1, W2, b2)), "keep": a}
+        sdf, cnt, ctx.state = _sdf_train_forward(x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first,
+                                                 query_locally, use_meas, use_valid, x.requires_grad)
         ctx.save_for_backward(x, feats, W1, b1, W2, b2)
         ctx.mark_non_differentiable(cnt)
         return sdf, cnt
@@ -910,6 +925,88 @@ def sdf_train(npm, decoder, x: torch.Tensor, query_locally: bool = True, use_onl
     l0, lo = decoder.layers[0], decoder.lout
     return _SdfTrain.apply(x, feats, l0.weight, l0.bias, lo.weight, lo.bias, npm, float(decoder.sdf_scale),
                            weighted_first, query_locally, use_only_measured_points, use_only_valid_points)
+
+
+# ---------------------------------------------------------------- fused finite-difference gradient
+def _declare_stencil(L):
+    if getattr(L, "_stencil_declared", False):
+        return
+    vp = C.c_void_p
+    L.pings_stencil_points.restype = C.c_int
+    L.pings_stencil_points.argtypes = [vp, C.c_int64, C.c_float, C.c_int, vp, vp]
+    L.pings_stencil_gradient.restype = C.c_int
+    L.pings_stencil_gradient.argtypes = [vp, vp, C.c_int64, C.c_float, C.c_int, vp, vp]
+    L.pings_stencil_gradient_backward.restype = C.c_int
+    L.pings_stencil_gradient_backward.argtypes = [vp, C.c_int64, C.c_float, C.c_int, vp, vp, vp]
+    L._stencil_declared = True
+
+
+class _NumGrad(torch.autograd.Function):
+    """`Mapper.get_numerical_gradient` (utils/mapper.py:2319-2370) as ONE graph node: shifted points, fused SDF query
+    and central differences forward (3 launches); the differences' adjoint and the fused SDF backward to the feature
+    table and the decoder backward.  The reference's op sequence is ~25 torch operators each way."""
+
+    @staticmethod
+    def forward(ctx, x, sdf_x, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, eps, two_side):
+        L = _L()
+        _declare_stencil(L)
+        q = x.detach()
+        if q.dtype != torch.float32 or not q.is_contiguous():
+            q = q.to(torch.float32).contiguous()
+        N = q.shape[0]
+        dev = q.device
+        blocks = 6 if two_side else 3
+        xs = torch.empty(blocks * N, 3, dtype=torch.float32, device=dev)
+        stream = _lib.stream_ptr(dev)
+        _lib.check(L.pings_stencil_points(q.data_ptr(), N, float(eps), int(two_side), xs.data_ptr(), stream),
+                   "pings_stencil_points")
+        s, _cnt, state = _sdf_train_forward(xs, feats, W1, b1, W2, b2, npm, sdf_scale, weighted_first, True, True,
+                                            False, False)
+        s0 = None
+        if not two_side:
+            s0 = sdf_x.detach()
+            if s0.dtype != torch.float32 or not s0.is_contiguous():
+                s0 = s0.to(torch.float32).contiguous()
+        grad = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        _lib.check(L.pings_stencil_gradient(s.data_ptr(), _lib.ptr(s0), N, float(eps), int(two_side), grad.data_ptr(),
+                                            stream), "pings_stencil_gradient")
+        ctx.state, ctx.N, ctx.eps, ctx.two_side = state, N, float(eps), bool(two_side)
+        ctx.need_s0 = (not two_side) and sdf_x is not None and sdf_x.requires_grad
+        return grad
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 12
+        L = _L()
+        N = ctx.N
+        dev = g.device
+        gg = g.detach()
+        if gg.dtype != torch.float32 or not gg.is_contiguous():
+            gg = gg.to(torch.float32).contiguous()
+        up = torch.empty((6 if ctx.two_side else 3) * N, dtype=torch.float32, device=dev)
+        up0 = torch.empty(N, dtype=torch.float32, device=dev) if ctx.need_s0 else None
+        _lib.check(L.pings_stencil_gradient_backward(gg.data_ptr(), N, ctx.eps, int(ctx.two_side), up.data_ptr(),
+                                                     _lib.ptr(up0), _lib.stream_ptr(dev)),
+                   "pings_stencil_gradient_backward")
+        _, (_gx, gF, gW1, gb1, gW2, gb2) = _sdf_first_order(ctx.state, up)
+        return (None, up0, gF, gW1, gb1, gW2, gb2) + (None,) * 5
+
+
+def numerical_gradient(npm, decoder, x, sdf_x=None, eps=0.02, two_side=True):
+    """Fused `Mapper.get_numerical_gradient`: [N,3] finite-difference SDF gradient at `x` (local query, measured points
+    only — the defaults `Mapper.sdf` uses), differentiable w.r.t. `local_geo_features`, the decoder and (one-sided)
+    `sdf_x`; `x` itself is treated as a constant (callers with `x.requires_grad` take the composed path)."""
+    cfg = getattr(npm, "config", None)
+    if cfg is not None and getattr(cfg, "layer_norm_on", False):
+        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
+    weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
+    if len(decoder.layers) != 1 or getattr(decoder, "use_leaky_relu", False):
+        raise NotImplementedError("numerical_gradient supports one-hidden-level ReLU decoders (every shipped config)")
+    l0, lo = decoder.layers[0], decoder.lout
+    return _NumGrad.apply(x, sdf_x, npm.local_geo_features, l0.weight, l0.bias, lo.weight, lo.bias, npm,
+                          float(decoder.sdf_scale), weighted_first, float(eps), bool(two_side))
 
 
 def install(neural_points_cls) -> None:

@@ -6,7 +6,7 @@ from conftest import rel_err
 
 # (N, IN, HID, OUT): the five GS decoders (pings.py:156-160), the SDF decoder, ragged / tiny sizes
 SHAPES = [(1000, 32, 128, 24), (777, 32, 128, 32), (4096, 33, 128, 8), (513, 19, 128, 24), (300, 16, 128, 24),
-          (2048, 35, 64, 1), (31, 11, 64, 1), (5000, 20, 64, 1), (333, 64, 64, 1), (100001, 35, 64, 1), (1, 8, 32, 3),
+          (2048, 35, 64, 1), (31, 11, 64, 1), (777, 19, 64, 1), (65, 1, 64, 1), (5000, 20, 64, 1), (333, 64, 64, 1), (100001, 35, 64, 1), (1, 8, 32, 3),
           (70000, 32, 128, 24)]
 
 

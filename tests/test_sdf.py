@@ -558,6 +558,63 @@ def test_hip_fused_mapper_sdf_double_backward_matches_reference_golden(golden_di
     torch.autograd.grad(gn.square().sum(), params)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_side", [True, False])
+@pytest.mark.parametrize("name", CASES)
+def test_fused_numerical_gradient_equals_the_reference_op_sequence(golden_dir, name, two_side):
+    """`get_numerical_gradient` as one graph node (stencil kernels around the fused query) against the reference's own
+    tensor-op sequence (utils/mapper.py:2319-2370) evaluated on the device: values and all parameter gradients."""
+    from types import SimpleNamespace as NS
+
+    from pings_amd import mapper_ops
+
+    st = load(golden_dir, name)
+    gpu = _gpu_map(st)
+    gpu.local_geo_features.requires_grad_(True)
+    t = lambda k: torch.nn.Parameter(T(st["dec." + k]).cuda())
+    d = NS(layers=[NS(weight=t("layers.0.weight"), bias=t("layers.0.bias"))],
+           lout=NS(weight=t("lout.weight"), bias=t("lout.bias")), sdf_scale=float(st["sdf_scale"]), use_leaky_relu=False)
+    m = _FakeMapper(gpu, d)
+    params = [gpu.local_geo_features, d.layers[0].weight, d.layers[0].bias, d.lout.weight, d.lout.bias]
+    xq = T(st["x"]).cuda()[:700]
+    eps = 0.05
+    up = torch.randn(700, 3, generator=torch.Generator().manual_seed(4)).cuda()
+
+    def run(x):
+        s0 = mapper_ops.sdf(m, x.detach())[0] if not two_side else None
+        g = mapper_ops.get_numerical_gradient(m, x, s0, eps=eps, two_side=two_side)
+        return g, torch.autograd.grad((g * up).sum(), params + ([s0] if s0 is not None and s0.requires_grad else []),
+                                      allow_unused=True)
+
+    g_f, d_f = run(xq)                                      # fused node
+    assert type(g_f.grad_fn).__name__ == "_NumGradBackward"
+    g_c, d_c = run(xq.clone().requires_grad_(True))         # composed path: the reference's op sequence on the fused sdf
+    assert type(g_c.grad_fn).__name__ != "_NumGradBackward"
+    # the composed path differentiates x as well, i.e. runs the forward kernel variant that also produces dS/dx: its S
+    # agrees to fp32 rounding, which the difference quotient (/ eps) amplifies
+    assert rel_err(g_f, g_c) <= 1e-4, rel_err(g_f, g_c)
+    for a, b in zip(d_f, d_c):
+        assert rel_err(a, b) <= 1e-4, rel_err(a, b)
+    with torch.no_grad():
+        g_n = mapper_ops.get_numerical_gradient(m, xq, mapper_ops.sdf(m, xq)[0], eps=eps, two_side=two_side)
+    assert torch.equal(g_n, g_f.detach())
+    # an empty batch (every Eikonal sample masked out) returns an empty gradient, as the reference's ops do
+    e = mapper_ops.get_numerical_gradient(m, xq[:0], mapper_ops.sdf(m, xq)[0][:0], eps=eps, two_side=two_side)
+    assert e.shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_query_feature_on_an_empty_batch_returns_empty_tensors(golden_dir):
+    """model/neural_gaussians.py:506-725 on zero query points returns empty tensors."""
+    from pings_amd import neural_points as hnp
+
+    st = load(golden_dir, CASES[0])
+    gpu = _gpu_map(st)
+    x = T(st["x"]).cuda()[:0]
+    geo, col, w, cnt, cert = hnp.query_feature(gpu, x, accumulate_stability=True)
+    assert geo.shape[0] == 0 and w.shape[0] == 0 and cnt.shape[0] == 0
+
+
 # ------------------------------------------------------------------ cell-block index (csrc/knn_blocks.hip)
 def _search_all_modes(cpu, gpu, x, hnp):
     out = []
