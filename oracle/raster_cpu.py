@@ -261,7 +261,7 @@ def bin_and_sort(geom, s: Settings):
 
 
 def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=None, rho=None,
-              return_debug=False):
+              return_debug=False, margins=False):
     """Forward pass.  All tensor inputs share one dtype (float32 or float64).
     surfel -> dict(color[3,H,W], normal[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P], contributions[P])
     3dgs   -> dict(color, depth (un-normalised), alpha, radii, n_touched[P])"""
@@ -290,6 +290,19 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
     n_touched = torch.zeros(P, dtype=torch.int32)
     n_contrib = torch.zeros(H, W, dtype=torch.int32)
     color_parts, normal_parts, depth_parts, alpha_parts = [], [], [], []
+    # margins=True: how far every pixel / Gaussian is from the nearest DISCRETE decision of the blend (relative distance
+    # to the alpha = 1/255 skip, the power = 0 skip, the T = 1e-4 stop, the 0.99 clamp, and for surfels the den = -1e-6
+    # test and the depth clamp to p_z +- 3 max(s)).  A pixel whose margin is within fp32 rounding can legitimately come
+    # out differently in another fp32 evaluation of the same formulas: the tests use this to IDENTIFY such pixels (and
+    # the Gaussians blended into them) instead of dropping the worst entries of a comparison.
+    # pixel_cond: first-order bound of what fp32 rounding of the footprint's quadratic form can move a blended channel
+    # of weight-one features by: sum over the blended records of w * eps32 * (|cx| dx^2 / 2 + |cz| dy^2 / 2 + |cy dx dy|)
+    # (a large, thin footprint evaluated far from its centre cancels terms of 1e3..1e4 to O(1): two fp32 evaluations
+    # with different rounding then disagree at 1e-3 although no decision flips).
+    pix_margin = torch.full((H, W), float("inf"), dtype=torch.float64)
+    g_margin = torch.full((P,), float("inf"), dtype=torch.float64)
+    pix_cond = torch.zeros((H, W), dtype=torch.float64)
+    g_cond = torch.zeros((P,), dtype=torch.float64)
 
     g_t = torch.from_numpy(g_idx)
     for ty in range(gy):
@@ -319,7 +332,20 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
                     stopped = torch.cumsum(stop.to(torch.int32), dim=0) > 0
                     incl = (~skip) & (~stopped)
                     last = torch.where(incl, torch.arange(1, b - a + 1)[:, None], 0).max(dim=0).values
+                if margins:
+                    with torch.no_grad():
+                        big = torch.full_like(al, float("inf"), dtype=torch.float64)
+                        live = ~stopped | stop            # records evaluated before (or at) the pixel's stop
+                        raw_d = (op[gi, None] * torch.exp(power)).double()
+                        m = torch.where(live & (power <= 0), (raw_d / ALPHA_MIN - 1.0).abs(), big)
+                        m = torch.minimum(m, torch.where(live & (raw_d >= ALPHA_MIN), power.double().abs(), big))
+                        m = torch.minimum(m, torch.where(live & ~skip, (Tincl.double() / T_EPS - 1.0).abs(), big))
+                        m = torch.minimum(m, torch.where(incl, (raw_d / ALPHA_MAX - 1.0).abs(), big))
+                        terms = (0.5 * (geom["conic_x"][gi, None].abs() * dx * dx + geom["conic_z"][gi, None].abs() * dy * dy)
+                                 + (geom["conic_y"][gi, None] * dx * dy).abs()).double()
+                        cond_rec = torch.where(incl, (al * Texcl).double() * terms * 1.1920929e-07, torch.zeros_like(big))
                 w = torch.where(incl, al * Texcl, torch.zeros_like(al))
+
                 Tfin = torch.prod(torch.where(incl, 1.0 - al, torch.ones_like(al)), dim=0)
                 c_t = (w[:, None, :] * colors[gi][:, :, None]).sum(0) + Tfin[None] * bg[:, None]
                 a_t = 1.0 - Tfin
@@ -331,6 +357,12 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
                         ok = den < -DEN_EPS
                     d = torch.where(ok, geom["q"][gi, None] / torch.where(ok, den, -torch.ones_like(den)),
                                     geom["pz"][gi, None].expand(-1, npix))
+                    if margins:
+                        with torch.no_grad():
+                            span = (geom["zhi"][gi, None] - geom["zlo"][gi, None]).double().clamp(min=1e-30)
+                            m = torch.minimum(m, torch.where(incl, (den.double() / DEN_EPS + 1.0).abs(), big))
+                            m = torch.minimum(m, torch.where(incl, (d - geom["zlo"][gi, None]).double().abs() / span, big))
+                            m = torch.minimum(m, torch.where(incl, (d - geom["zhi"][gi, None]).double().abs() / span, big))
                     d = torch.minimum(torch.maximum(d, geom["zlo"][gi, None]), geom["zhi"][gi, None])
                     nvec = torch.stack([geom["nx"][gi], geom["ny"][gi], geom["nz"][gi]], dim=1)
                     n_t = (w[:, None, :] * nvec[:, :, None]).sum(0)
@@ -343,6 +375,18 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
                         touched = (incl & (Tincl > 0.5)).sum(1).to(torch.int32)
                         n_touched.index_add_(0, gi, touched)
                 n_contrib[y0:y1, x0:x1] = last.reshape(y1 - y0, x1 - x0).to(torch.int32)
+                if margins:
+                    with torch.no_grad():
+                        pm = m.min(dim=0).values
+                        pix_margin[y0:y1, x0:x1] = pm.reshape(y1 - y0, x1 - x0)
+                        # a flip in a pixel moves the gradient of every record evaluated there (transmittance in front
+                        # of the ones behind it, the blended-behind term of the ones in front)
+                        gm = torch.where(live, pm[None].expand_as(m), big).min(dim=1).values
+                        g_margin = g_margin.index_reduce(0, gi, gm, "amin", include_self=True)
+                        pc = cond_rec.sum(dim=0)
+                        pix_cond[y0:y1, x0:x1] = pc.reshape(y1 - y0, x1 - x0)
+                        gc_ = torch.where(live, pc[None].expand_as(m), torch.zeros_like(m)).max(dim=1).values
+                        g_cond = g_cond.index_reduce(0, gi, gc_, "amax", include_self=True)
             else:
                 c_t = bg[:, None].expand(3, npix)
                 n_t = torch.zeros(3, npix, dtype=dt)
@@ -380,6 +424,8 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
     if return_debug:
         out.update(geom=geom, point_list=g_idx, ranges=ranges, n_contrib=n_contrib,
                    tiles_touched=geom["tiles_touched"])
+    if margins:
+        out.update(pixel_margin=pix_margin, gaussian_margin=g_margin, pixel_cond=pix_cond, gaussian_cond=g_cond)
     return out
 
 

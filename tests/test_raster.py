@@ -14,14 +14,14 @@ from scenes import hip_settings, make_scene, oracle_settings
 F32 = lambda t: t.to(torch.float32)
 
 
-def _oracle(sc, dtype, mode, front_only, grads=False, scale_modifier=1.0):
+def _oracle(sc, dtype, mode, front_only, grads=False, scale_modifier=1.0, margins=False):
     so = oracle_settings(sc, dtype, mode, front_only, scale_modifier)
     names = ["means", "col", "op", "scales", "rot"]
     leaves = {k: sc[k].to(dtype).clone().requires_grad_(grads) for k in names}
     theta = torch.zeros(3, dtype=dtype, requires_grad=grads)
     rho = torch.zeros(3, dtype=dtype, requires_grad=grads)
     out = R.rasterize(leaves["means"], leaves["col"], leaves["op"], leaves["scales"], leaves["rot"], so,
-                      theta if grads else None, rho if grads else None, return_debug=True)
+                      theta if grads else None, rho if grads else None, return_debug=True, margins=margins)
     return out, leaves, theta, rho
 
 
@@ -186,6 +186,32 @@ def test_forward_indices_bit_exact_and_images_close(mode, front_only, seed, size
     assert (mv.cpu() == R.mark_visible(F32(sc["means"]), so)).all()
 
 
+MARGIN_TOL = 3e-5   # relative distance to a discrete blend decision below which two fp32 evaluations may disagree
+COND_TOL = 2e-5     # estimated fp32 rounding of the footprint's quadratic form, in units of a blended channel
+
+
+def _undecidable(o32, o64=None):
+    """(pixel mask [H,W], Gaussian mask [P]) of what fp32 cannot decide: pixels within MARGIN_TOL of a discrete decision
+    of the blend or whose quadratic-form conditioning exceeds COND_TOL (oracle/raster_cpu.py `margins=True`), and —
+    against the fp64 oracle only — the tiles whose (tile, depth, index) lists differ between the fp32 and fp64 oracle
+    (a footprint bounding box within rounding of a tile boundary); a Gaussian is flagged when it is evaluated in a
+    flagged pixel.  The HIP kernels are compared at 1e-4 on everything outside these sets."""
+    pm, pc = o32["pixel_margin"], o32["pixel_cond"]
+    pix = (pm < MARGIN_TOL) | (pc > COND_TOL)
+    gs = (o32["gaussian_margin"] < MARGIN_TOL) | (o32["gaussian_cond"] > COND_TOL)
+    if o64 is not None:
+        H, W = pm.shape
+        gx = (W + 15) // 16
+        r32, r64, l32, l64 = o32["ranges"], o64["ranges"], o32["point_list"], o64["point_list"]
+        for t in range(r32.shape[0]):
+            a, b = l32[r32[t, 0]:r32[t, 1]], l64[r64[t, 0]:r64[t, 1]]
+            if a.shape != b.shape or not np.array_equal(a, b):
+                ty, tx = divmod(t, gx)
+                pix[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = True
+                gs[torch.from_numpy(np.union1d(a, b))] = True
+    return pix, gs
+
+
 def _oracle_grads(sc, dt, mode, front_only, seeds=5):
     """Oracle forward + autograd backward in dtype `dt` against fixed random upstream gradients."""
     o, leaves, theta, rho = _oracle(sc, dt, mode, front_only, grads=True)
@@ -240,6 +266,32 @@ def _max_without_worst(a, b, k):
     if k > 0 and d.numel() > k:
         d = torch.topk(d, d.numel() - k, largest=False).values
     return d.max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def _assert_grad_gate_identified(names, got, ref64, ref32, what, g_flag):
+    """Dense scenes: instead of dropping the worst 0.1 % of every tensor (round 2), the Gaussians that are evaluated in
+    an UNDECIDABLE pixel are identified (`_undecidable`) and every other Gaussian must meet the plain gate
+    max(1e-4, 1.5 x the fp32 oracle's own distance on the same rows) in the max norm; the flagged rows keep round 2's
+    gate.  Pose gradients are sums over every Gaussian: 5e-4."""
+    keep = ~g_flag
+    print(f"\n[{what}] {int(g_flag.sum())} of {g_flag.numel()} Gaussians are evaluated in an undecidable pixel; errors vs the fp64 "
+          f"oracle on the OTHERS: max-norm HIP | fp32 oracle (scale = max|ref| of the whole tensor)")
+    for name, a, b64, b32 in zip(names, got, ref64, ref32):
+        a, b64, b32 = a.detach().double().cpu(), b64.detach().double().cpu(), b32.detach().double().cpu()
+        scale = max(b64.abs().max().item(), 1e-30)
+        if a.numel() <= 8:
+            eh, eo = (a - b64).abs().max().item() / scale, (b32 - b64).abs().max().item() / scale
+            print(f"  {name:7s} {eh:9.2e} | {eo:9.2e}")
+            assert eh <= max(5e-4, 1.5 * eo), (what, name, eh, eo)
+            continue
+        a2, r2, o2 = a.reshape(a.shape[0], -1), b64.reshape(a.shape[0], -1), b32.reshape(a.shape[0], -1)
+        eh = (a2[keep] - r2[keep]).abs().max().item() / scale
+        eo = (o2[keep] - r2[keep]).abs().max().item() / scale
+        ef = (a2[g_flag] - r2[g_flag]).abs().max().item() / scale if g_flag.any() else 0.0
+        print(f"  {name:7s} {eh:9.2e} | {eo:9.2e}     flagged rows: {ef:9.2e}")
+        assert eh <= max(1e-4, 1.5 * eo), (what, name, eh, eo)
+        k = max(8, int(1e-3 * a.numel()))
+        assert _max_without_worst(a, b64, k) <= max(1e-4, 1.5 * _errs(b32, b64)[0]), (what, name)
 
 
 def _assert_grad_gate(names, got, ref64, ref32, what, flips_allowed=False):
@@ -303,8 +355,9 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
     else:
         parts = (street_scene if kind == "street" else room_scene)(P, device="cpu", seed=3)
     sc = scene_as_dict(*parts, W, H, fx)
-    o32, *_ = _oracle(sc, torch.float32, "surfel", True)
+    o32, *_ = _oracle(sc, torch.float32, "surfel", True, margins=True)
     o64, names, ref64, ups = _oracle_grads(sc, torch.float64, "surfel", True)
+    pix_flag, g_flag = _undecidable(o32, o64)
     _, _, ref32, _ = _oracle_grads(sc, torch.float32, "surfel", True)
     hr, prep, fs, radii, per_g = _hip_forward(sc, "surfel", True)
     pl, rg, fT, nc = hr.debug_lists(fs)
@@ -327,8 +380,46 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
         # size of a flip: one contribution of alpha ~ 1/255 in the blended channels; the alpha-normalised depth of a
         # nearly transparent pixel can move by centimetres (<= 1e-2 of the largest depth)
         assert e64[0] <= 1e-4 or e64[0] <= (1e-2 if k == "depth" else 1.1 / 255), k
+        if k != "contributions":
+            # ... and the flips are IDENTIFIED: every pixel outside the undecidable set is within 1e-4 in the max norm
+            ref = o64[k].double()
+            err = (t.detach().double().cpu() - ref).abs().amax(0) / max(ref.abs().max().item(), 1e-30)
+            assert err[~pix_flag].max().item() <= 1e-4, (k, err[~pix_flag].max().item(), int(pix_flag.sum()))
+    print(f"  undecidable pixels: {int(pix_flag.sum())} of {pix_flag.numel()}")
     _, got, _ = _hip_grads(sc, "surfel", True, ups)
-    _assert_grad_gate(names, got, ref64, ref32, f"{kind} {P}@{W}x{H}", flips_allowed=True)
+    _assert_grad_gate_identified(names, got, ref64, ref32, f"{kind} {P}@{W}x{H}", g_flag)
+
+
+@pytest.mark.gpu
+def test_c2_full_size_forward_matches_the_fp32_oracle():
+    """BASELINE.json C2 at its FULL size (Replica-like room, 200k surfels, 640x480, the bench's `raster_c2` workload)
+    against the fp32 oracle forward: radii, per-tile lists (prefixes under the occlusion bound) and per-pixel
+    contributor counts exact; colour / normal / depth / alpha within 1e-4 on every pixel that fp32 can decide, the
+    undecidable ones identified, counted and bounded by one alpha = 1/255 contribution (VERDICT r2 #5a)."""
+    from scenes import room_scene, scene_as_dict
+
+    P, W, H, fx = 200_000, 640, 480, 600.0
+    sc = scene_as_dict(*room_scene(P, device="cpu", seed=1), W, H, fx)
+    o32, *_ = _oracle(sc, torch.float32, "surfel", True, margins=True)
+    pix_flag, _ = _undecidable(o32)
+    hr, prep, fs, radii, per_g = _hip_forward(sc, "surfel", True)
+    pl, rg, fT, nc = hr.debug_lists(fs)
+    assert (radii.cpu() == o32["radii"]).all()
+    _check_list_prefixes(pl, rg, nc, o32, W, H)
+    nc_bad = nc.cpu() != o32["n_contrib"]
+    assert not (nc_bad & ~pix_flag).any()                 # a count may only differ where the stop rule is undecidable
+    print(f"\n[C2 room {P}@{W}x{H}] instances {len(pl)} (oracle, un-culled: {len(o32['point_list'])}); undecidable "
+          f"pixels {int(pix_flag.sum())} of {pix_flag.numel()}; n_contrib differs at {int(nc_bad.sum())} of them")
+    for k, t in (("color", fs.color), ("depth", fs.depth), ("alpha", fs.alpha), ("normal", fs.normal)):
+        ref = o32[k].double()
+        scale = max(ref.abs().max().item(), 1e-30)
+        err = (t.detach().double().cpu() - ref).abs().amax(0) / scale
+        print(f"  {k:7s} max-norm error on decidable pixels {err[~pix_flag].max().item():.2e}, on the others "
+              f"{(err[pix_flag].max().item() if pix_flag.any() else 0.0):.2e}")
+        assert err[~pix_flag].max().item() <= 1e-4, k
+        assert err.max().item() <= (1e-2 if k == "depth" else 1.1 / 255), k
+    e = _errs(per_g, o32["contributions"])
+    assert e[1] <= 1e-4, e
 
 
 @pytest.mark.gpu
