@@ -576,6 +576,28 @@ PINGS_API size_t pings_voxel_downsample_scratch_bytes(int64_t N);
  * reference's linear voxel id; *count (HOST) = number of voxels.  Synchronises `stream` once. */
 PINGS_API int pings_voxel_downsample(const float* points, int64_t N, float voxel_size, void* scratch,
                                      int64_t* sample_idx, int64_t* count, void* stream);
+/* `voxel_down_sample_min_value_torch(points, voxel_size, value)` (utils/tools.py:970-1009): per occupied voxel the
+ * point with the smallest `value` (1000 bins of value / max(value), ties by index); value NULL = the distance to the
+ * voxel centre (pings_voxel_downsample).  Same output order, same single synchronisation. */
+PINGS_API int pings_voxel_downsample_min_value(const float* points, const float* value, int64_t N, float voxel_size,
+                                               void* scratch, int64_t* sample_idx, int64_t* count, void* stream);
+/* Loop-closure maintenance of the map (model/neural_gaussians.py:871-1010):
+ *   pings_map_prune_mask  prune[i] = |travel[cur_ts] - travel[ts_update[i]]| > diff_travel && certainty[i] < threshold
+ *                         (:873-880; the caller counts, compacts the rows with pings_gather_rows and rebuilds the hash)
+ *   pings_map_adjust      in place: p <- R p + t, q <- quat(R) (x) q with pose_diff[ts] (ts = create, or the mid
+ *                         timestamp when use_mid_ts; :911-937); pose_diff is [num_poses, 4, 4] row-major, float64 when
+ *                         pose_is_f64 (the quaternion part is then evaluated in float64 and cast, as the reference's
+ *                         type promotion does) else float32
+ *   pings_map_rehash      table[:] = -1; table[hash(points[v_j])] = v_j with v_j = sample_idx[j] (NULL: j) for
+ *                         j < M, duplicates: the last j wins (:949-1000); slot_scratch: M int64 */
+PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int32_t cur_ts, const int32_t* point_ts_update,
+                                   const float* point_certainties, float diff_travel_dist_local,
+                                   float prune_certainty_thre, uint8_t* prune_mask, void* stream);
+PINGS_API int pings_map_adjust(int64_t N, float* neural_points, float* point_orientations, const int32_t* point_ts_create,
+                               const int32_t* point_ts_update, int32_t use_mid_ts, const void* pose_diff,
+                               int32_t pose_is_f64, int64_t num_poses, void* stream);
+PINGS_API int pings_map_rehash(const float* neural_points, const int64_t* sample_idx, int64_t M, float resolution,
+                               int64_t buffer_size, int64_t* table, int64_t* slot_scratch, void* stream);
 PINGS_API size_t pings_map_update_scratch_bytes(int64_t M, int64_t num_points);
 /* Inserts the M voxel representatives.  table[buffer_size] int64; travel_dist NULL = no travel-distance window
  * (temporal_local_map_on False); sample_colors / point_colors nullable together.  update_mask[M] (uint8, nullable)

@@ -366,6 +366,90 @@ def make_map(R):
         np.savez_compressed(OUT / f"map_{name}.npz", **out)
 
 
+# ---------------------------------------------------------------- G12 loop-closure map maintenance
+def make_map_closure(R):
+    """G12: `prune_map`, `adjust_map`, `recreate_hash` (model/neural_gaussians.py:871-1010) driven through the
+    reference's own `NeuralPoints` after the four frames of G8 (same seeds: the map is the one of map_*.npz): prune by
+    certainty / travel distance, a pose-graph correction per timestamp (float64 poses, as PIN-SLAM keeps them), hash
+    re-creation keeping every point (by timestamp) and merging to one point per voxel (by certainty)."""
+    from utils.tools import voxel_down_sample_min_value_torch  # type: ignore
+
+    for name, case in MAP_CASES.items():
+        gen = torch.Generator().manual_seed(len(name) * 7)
+        torch.manual_seed(3)
+        cfg = R.make_config(**case["cfg"])
+        cfg.local_map_radius = 4.0
+        cfg.sorrounding_map_radius = 6.0
+        cfg.color_on = True
+        npm = R.NeuralPoints(cfg)
+        nf = case["frames"]
+        npm.travel_dist = torch.tensor([0.0, 0.8, 1.7, 2.9, 3.5][:nf + 1], dtype=torch.float32)
+        npm.diff_travel_dist_local = case["diff_travel"]
+        for ts in range(nf):                                   # the frames of G8, op for op
+            n = 3000
+            pts = _wavy_points(n, gen, extent=5.0) + torch.tensor([0.7 * ts, 0.1 * ts, 0.0])
+            pts = pts + 0.01 * torch.randn(n, 3, generator=gen)
+            cols = torch.rand(n, 3, generator=gen)
+            cols[torch.rand(n, generator=gen) < 0.2, 0] = -1.0
+            sensor = torch.tensor([0.7 * ts, 0.1 * ts, 0.5])
+            npm.update(pts, cols, None, None, None, cur_ts=ts, is_reliable=(ts != 1))
+            npm.reset_local_map(sensor, torch.eye(3), cur_ts=ts)
+            with torch.no_grad():
+                npm.local_geo_features += 0.01 * (ts + 1)
+                npm.local_color_features -= 0.02 * (ts + 1)
+            npm.local_point_certainties = npm.local_point_certainties + 0.5
+            npm.local_point_ts_update = torch.full_like(npm.local_point_ts_update, ts)
+            npm.assign_local_to_global()
+        out = {}
+
+        def snap(tag):
+            for k in ("neural_points", "point_orientations", "point_ts_create", "point_ts_update", "point_certainties",
+                      "point_colors", "valid_color_mask", "valid_gs_mask", "free_gs_mask", "geo_features",
+                      "color_features"):
+                out[f"{tag}_{k}"] = _np(getattr(npm, k))
+            tab = npm.buffer_pt_index
+            nz = torch.nonzero(tab >= 0).flatten()
+            out[f"{tag}_table_slots"], out[f"{tag}_table_vals"] = _np(nz), _np(tab[nz])
+
+        cur_ts = nf - 1
+        # certainties with some spread, so that the prune threshold and the certainty merge have something to decide
+        npm.point_certainties = npm.point_certainties + torch.rand(npm.count(), generator=gen)
+        out["certainties_in"] = _np(npm.point_certainties)
+        thre, min_count = 0.9, 20
+        out["prune_thre"], out["min_prune_count"] = np.float64(thre), np.int64(min_count)
+        pruned = npm.prune_map(thre, min_count)
+        out["pruned"] = np.bool_(pruned)
+        snap("prune")
+        # pose-graph correction: one small rigid motion per timestamp, float64
+        g64 = torch.Generator().manual_seed(77)
+        pose = torch.eye(4, dtype=torch.float64).repeat(nf, 1, 1)
+        for t in range(nf):
+            w = 0.05 * (torch.rand(3, generator=g64, dtype=torch.float64) - 0.5) * (t + 1)
+            K = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
+            pose[t, :3, :3] = torch.linalg.matrix_exp(K)
+            pose[t, :3, 3] = 0.2 * (torch.rand(3, generator=g64, dtype=torch.float64) - 0.5) * (t + 1)
+        out["pose_diff"] = _np(pose)
+        npm.adjust_map(pose)
+        snap("adjust")
+        sensor = torch.tensor([0.7 * cur_ts, 0.1 * cur_ts, 0.5])
+        out["sensor"] = _np(sensor)
+        ts_used = ((npm.point_ts_create + npm.point_ts_update) / 2).int() if cfg.use_mid_ts else npm.point_ts_create
+        out["keep_sample_idx"] = _np(voxel_down_sample_min_value_torch(npm.neural_points, npm.resolution,
+                                                                       torch.abs(ts_used - cur_ts).float()))
+        npm.recreate_hash(sensor, torch.eye(3), kept_points=True, with_ts=True, cur_ts=cur_ts)
+        snap("keep")
+        out["keep_local_mask"], out["keep_global2local"] = _np(npm.local_mask), _np(npm.global2local)
+        out["merge_sample_idx"] = _np(voxel_down_sample_min_value_torch(
+            npm.neural_points, npm.resolution, npm.point_certainties.max() - npm.point_certainties))
+        npm.recreate_hash(sensor, torch.eye(3), kept_points=False, with_ts=False, cur_ts=cur_ts)
+        snap("merge")
+        out["merge_local_mask"], out["merge_global2local"] = _np(npm.local_mask), _np(npm.global2local)
+        out["merge_local_geo_features"] = _np(npm.local_geo_features)
+        print(f"mapclosure_{name}: pruned={pruned} points after prune/merge = {out['prune_neural_points'].shape[0]} / "
+              f"{out['merge_neural_points'].shape[0]}")
+        np.savez_compressed(OUT / f"mapclosure_{name}.npz", **out)
+
+
 # ---------------------------------------------------------------- G9 tracker registration step
 def make_tracker(R):
     """G9: `implicit_reg` on synthetic residuals and `Tracker.query_source_points` (SDF head) on the maps of G1-G3."""
@@ -501,7 +585,7 @@ def make_mesher(R):
 
 
 GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map,
-          "tracker": make_tracker, "imgloss": make_imgloss, "mesher": make_mesher}
+          "tracker": make_tracker, "imgloss": make_imgloss, "mesher": make_mesher, "mapclosure": make_map_closure}
 
 
 def main(argv):

@@ -192,3 +192,88 @@ def assign_local_to_global(m):
     m.geo_features[lm] = m.local_geo_features
     if m.color_features is not None:
         m.color_features[lm] = m.local_color_features
+
+
+# ---------------------------------------------------------------- loop closure (model/neural_gaussians.py:871-1010)
+def voxel_down_sample_min_value(points: torch.Tensor, voxel_size: float, value: torch.Tensor) -> torch.Tensor:
+    """utils/tools.py:970-1009, op for op (fp32): per voxel the point with the smallest `value` (1000 bins), ties by
+    index.  An all-zero `value` (0 / 0 in the reference) bins to 0."""
+    q = 1000
+    offset = torch.floor(points.min(dim=0)[0] / voxel_size).long()
+    grid = torch.floor(points / voxel_size)
+    grid = grid.long() - offset
+    v_size = grid.max()
+    grid_idx = grid[:, 0] + grid[:, 1] * v_size + grid[:, 2] * v_size * v_size
+    unique, inverse = torch.unique(grid_idx, return_inverse=True)
+    idx_d = torch.arange(inverse.size(0), dtype=inverse.dtype)
+    off = 10 ** len(str(idx_d.max().item()))
+    vmax = value.max()
+    vb = (value / vmax * (q - 1)).long() if float(vmax) > 0 else torch.zeros_like(value, dtype=torch.int64)
+    idx_d = idx_d + vb * off
+    idx = torch.empty(unique.shape, dtype=inverse.dtype).scatter_reduce_(0, inverse, idx_d, reduce="amin",
+                                                                         include_self=False)
+    return idx % off
+
+
+def _rows(m, rows: torch.Tensor):
+    n_old = m.neural_points.shape[0]
+    for name in ("neural_points", "point_orientations", "point_ts_create", "point_ts_update", "point_certainties",
+                 "point_colors", "valid_color_mask", "valid_gs_mask", "free_gs_mask"):
+        t = getattr(m, name, None)
+        if t is not None:
+            setattr(m, name, t[rows])
+    pad = torch.cat((rows, torch.tensor([n_old])))
+    m.geo_features = m.geo_features[pad]
+    if m.color_features is not None:
+        m.color_features = m.color_features[pad]
+
+
+def prune_map(m, prune_certainty_thre, min_prune_count=500) -> bool:
+    """neural_gaussians.py:871-909."""
+    diff = torch.abs(m.travel_dist[m.cur_ts] - m.travel_dist[m.point_ts_update.long()])
+    prune = (diff > m.diff_travel_dist_local) & (m.point_certainties < prune_certainty_thre)
+    if int(prune.sum()) > min_prune_count:
+        _rows(m, torch.nonzero(~prune).flatten())
+        return True
+    return False
+
+
+def adjust_map(m, pose_diff: torch.Tensor) -> None:
+    """neural_gaussians.py:911-937 with utils/tools.py:754-773 (rotmat_to_quat), :811-829 (quat_multiply), :903-921."""
+    m.after_pgo = True
+    ts = ((m.point_ts_create + m.point_ts_update) / 2).int() if m.use_mid_ts else m.point_ts_create
+    T = pose_diff[ts.long()]
+    rot, tr = T[:, :3, :3].to(m.neural_points), T[:, :3, 3:].to(m.neural_points)
+    m.neural_points = (torch.bmm(rot, m.neural_points.unsqueeze(-1)) + tr).squeeze(-1)
+    Rm = pose_diff[:, :3, :3]
+    qw = torch.sqrt(1.0 + Rm[:, 0, 0] + Rm[:, 1, 1] + Rm[:, 2, 2]) / 2.0
+    dq = torch.stack((qw, (Rm[:, 2, 1] - Rm[:, 1, 2]) / (4.0 * qw), (Rm[:, 0, 2] - Rm[:, 2, 0]) / (4.0 * qw),
+                      (Rm[:, 1, 0] - Rm[:, 0, 1]) / (4.0 * qw)), dim=1)[ts.long()]
+    w1, x1, y1, z1 = torch.unbind(dq, dim=1)
+    w2, x2, y2, z2 = torch.unbind(m.point_orientations, dim=1)
+    m.point_orientations = torch.stack((w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2),
+                                       dim=1).to(m.point_orientations)
+
+
+def recreate_hash(m, sensor_position, sensor_orientation=None, kept_points: bool = True, with_ts: bool = True, cur_ts=0):
+    """neural_gaussians.py:939-1010 (duplicate table slots: the last representative wins)."""
+    res = m.resolution
+    m.buffer_pt_index = torch.full((m.buffer_size,), -1, dtype=torch.int64)
+    if with_ts:
+        ts_used = ((m.point_ts_create + m.point_ts_update) / 2).int() if m.use_mid_ts else m.point_ts_create
+        value = torch.abs(ts_used - cur_ts).float()
+    else:
+        value = m.point_certainties.max() - m.point_certainties
+    sample_idx = voxel_down_sample_min_value(m.neural_points, res, value)
+    if kept_points:
+        vals = sample_idx
+    else:
+        _rows(m, sample_idx)
+        vals = torch.arange(m.neural_points.shape[0], dtype=torch.int64)
+    hv = hash_slots(m.neural_points[vals], res, m.buffer_size)
+    slot = torch.where(hv < 0, hv + m.buffer_size, hv)
+    keep = _last_wins(slot, m.buffer_size)
+    m.buffer_pt_index[slot[keep]] = vals[keep]
+    if sensor_position is not None:
+        reset_local_map(m, sensor_position, cur_ts)

@@ -52,6 +52,7 @@ ALPHA_MIN = 1.0 / 255.0
 T_EPS = 1e-4
 DEPTH_ALPHA_EPS = 1e-10
 DEN_EPS = 1e-6
+UNC_FACTOR = 1.0   # margins=True: multiples of the first-order fp32 uncertainty taken off every decision margin
 
 
 @dataclass
@@ -295,10 +296,12 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
     # test and the depth clamp to p_z +- 3 max(s)).  A pixel whose margin is within fp32 rounding can legitimately come
     # out differently in another fp32 evaluation of the same formulas: the tests use this to IDENTIFY such pixels (and
     # the Gaussians blended into them) instead of dropping the worst entries of a comparison.
-    # pixel_cond: first-order bound of what fp32 rounding of the footprint's quadratic form can move a blended channel
-    # of weight-one features by: sum over the blended records of w * eps32 * (|cx| dx^2 / 2 + |cz| dy^2 / 2 + |cy dx dy|)
-    # (a large, thin footprint evaluated far from its centre cancels terms of 1e3..1e4 to O(1): two fp32 evaluations
-    # with different rounding then disagree at 1e-3 although no decision flips).
+    # pixel_cond: first-order bound of what fp32 rounding can move a blended channel of weight-one features by: sum over
+    # the blended records of w * u, u = eps32 * (|cx| dx^2 / 2 + |cz| dy^2 / 2 + |cy dx dy| + kappa |power| + 4) (a large,
+    # thin footprint evaluated far from its centre cancels terms of 1e3..1e4 to O(1), and its conic carries the
+    # cancellation of det = cxx cyy - cxy^2: two fp32 evaluations with different rounding then disagree at 1e-3 although
+    # no decision flips).  The decision margins are reduced by UNC_FACTOR u: a threshold 1e-3 away is still undecidable for a
+    # record whose alpha is only known to 1e-3.
     pix_margin = torch.full((H, W), float("inf"), dtype=torch.float64)
     g_margin = torch.full((P,), float("inf"), dtype=torch.float64)
     pix_cond = torch.zeros((H, W), dtype=torch.float64)
@@ -337,13 +340,22 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
                         big = torch.full_like(al, float("inf"), dtype=torch.float64)
                         live = ~stopped | stop            # records evaluated before (or at) the pixel's stop
                         raw_d = (op[gi, None] * torch.exp(power)).double()
-                        m = torch.where(live & (power <= 0), (raw_d / ALPHA_MIN - 1.0).abs(), big)
-                        m = torch.minimum(m, torch.where(live & (raw_d >= ALPHA_MIN), power.double().abs(), big))
-                        m = torch.minimum(m, torch.where(live & ~skip, (Tincl.double() / T_EPS - 1.0).abs(), big))
-                        m = torch.minimum(m, torch.where(incl, (raw_d / ALPHA_MAX - 1.0).abs(), big))
-                        terms = (0.5 * (geom["conic_x"][gi, None].abs() * dx * dx + geom["conic_z"][gi, None].abs() * dy * dy)
-                                 + (geom["conic_y"][gi, None] * dx * dy).abs()).double()
-                        cond_rec = torch.where(incl, (al * Texcl).double() * terms * 1.1920929e-07, torch.zeros_like(big))
+                        # u: first-order fp32 uncertainty of a record's alpha (relative): rounding of the quadratic
+                        # form's terms, plus the conic's own conditioning (det = cxx cyy - cxy^2 cancels for a thin
+                        # footprint: kappa = cxx cyy / det) scaled by |power|, plus a few ulp of the exp / products
+                        cx_, cy_, cz_ = (geom[k_][gi, None].double() for k_ in ("conic_x", "conic_y", "conic_z"))
+                        terms = 0.5 * (cx_.abs() * dx.double() ** 2 + cz_.abs() * dy.double() ** 2) \
+                            + (cy_ * dx.double() * dy.double()).abs()
+                        kappa = (cx_ * cz_).abs() / (cx_ * cz_ - cy_ * cy_).abs().clamp(min=1e-300)
+                        u = 1.1920929e-07 * (terms + kappa * power.double().abs() + 4.0)
+                        aa = torch.where(skip, torch.zeros_like(raw_d), raw_d.clamp(max=ALPHA_MAX))
+                        uT = torch.cumsum(u * aa / (1.0 - aa), dim=0) + 1.1920929e-07 * torch.arange(1, b - a + 1)[:, None]
+                        eff = lambda dist, unc: (dist - UNC_FACTOR * unc).clamp(min=0.0)   # distance left after the rounding allowance
+                        m = torch.where(live & (power <= 0), eff((raw_d / ALPHA_MIN - 1.0).abs(), u), big)
+                        m = torch.minimum(m, torch.where(live & (raw_d >= ALPHA_MIN), eff(power.double().abs(), u), big))
+                        m = torch.minimum(m, torch.where(live & ~skip, eff((Tincl.double() / T_EPS - 1.0).abs(), uT), big))
+                        m = torch.minimum(m, torch.where(incl, eff((raw_d / ALPHA_MAX - 1.0).abs(), u), big))
+                        cond_rec = torch.where(incl, (al * Texcl).double() * u, torch.zeros_like(big))
                 w = torch.where(incl, al * Texcl, torch.zeros_like(al))
 
                 Tfin = torch.prod(torch.where(incl, 1.0 - al, torch.ones_like(al)), dim=0)

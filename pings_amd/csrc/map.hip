@@ -50,12 +50,14 @@ __device__ inline float cell_dist(const float* __restrict__ p, float voxel, floa
 }
 
 __global__ __launch_bounds__(256) void vds_bounds_kernel(const float* __restrict__ pts, i64 N, float voxel,
-                                                         Bounds* __restrict__ partial) {
+                                                         Bounds* __restrict__ partial,
+                                                         const float* __restrict__ value = nullptr) {
   __shared__ float red[7][4];
   float v[7] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (i64)gridDim.x * blockDim.x) {
     float g[3];
-    const float d = cell_dist(pts + 3 * i, voxel, g);
+    float d = cell_dist(pts + 3 * i, voxel, g);
+    if (value) d = value[i];                          // voxel_down_sample_min_value_torch: the caller's value
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       v[a] = fminf(v[a], pts[3 * i + a]);
@@ -118,15 +120,18 @@ __global__ void vds_finish_bounds_kernel(const Bounds* __restrict__ partial, int
 
 __global__ __launch_bounds__(256) void vds_key_kernel(const float* __restrict__ pts, i64 N, float voxel,
                                                       const GridInfo* __restrict__ info, i64* __restrict__ key,
-                                                      unsigned long long* __restrict__ val) {
+                                                      unsigned long long* __restrict__ val,
+                                                      const float* __restrict__ value = nullptr) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const GridInfo gi = *info;
   float g[3];
-  const float d = cell_dist(pts + 3 * i, voxel, g);
+  float d = cell_dist(pts + 3 * i, voxel, g);
+  if (value) d = value[i];
   const i64 gx = (i64)g[0] - gi.off[0], gy = (i64)g[1] - gi.off[1], gz = (i64)g[2] - gi.off[2];
   key[i] = gx + gy * gi.vsize + gz * gi.vsize * gi.vsize;        // the reference's (aliasing) linear voxel id
-  const i64 bin = (i64)(d / gi.dmax * (float)(kQuant - 1));      // (dist / dist.max() * 999).long()
+  // (dist / dist.max() * 999).long(); an all-zero value vector (0 / 0 in the reference, utils/tools.py:996) bins to 0
+  const i64 bin = gi.dmax > 0.f ? (i64)(d / gi.dmax * (float)(kQuant - 1)) : 0;
   val[i] = ((unsigned long long)bin << 32) | (unsigned long long)(uint32_t)i;
 }
 
@@ -389,12 +394,131 @@ __global__ __launch_bounds__(256) void scatter_bytes_kernel(const uint8_t* __res
 
 inline unsigned blocks_for(i64 n) { return (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1); }
 
+// ------------------------------------------------------------------ loop-closure maintenance
+// prune_map (:871-909): prune = |travel[cur] - travel[ts_update]| > diff_travel  and  certainty < threshold
+__global__ __launch_bounds__(256) void prune_mask_kernel(i64 N, const float* __restrict__ travel, int cur_ts,
+                                                         const int32_t* __restrict__ ts_update,
+                                                         const float* __restrict__ cert, float diff_travel, float thre,
+                                                         uint8_t* __restrict__ prune) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float d = fabsf(travel[cur_ts] - travel[ts_update[i]]);
+  prune[i] = (d > diff_travel && cert[i] < thre) ? 1 : 0;
+}
+
+// adjust_map (:911-937): p <- R p + t (fp32, the pose cast to the points' dtype first), q <- quat(R) (x) q with the
+// rotation quaternion and the product evaluated in the POSE's dtype (the reference promotes: float64 poses give a
+// float64 product that is cast back), pose = pose_diff[ts] with ts = ((create + update) / 2).int() or create.
+template <typename PT>
+__global__ __launch_bounds__(256) void adjust_kernel(i64 N, float* __restrict__ pts, float* __restrict__ quat,
+                                                     const int32_t* __restrict__ ts_create,
+                                                     const int32_t* __restrict__ ts_update, int use_mid_ts,
+                                                     const PT* __restrict__ pose, i64 T) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  i64 ts = use_mid_ts ? (i64)(int32_t)((float)(ts_create[i] + ts_update[i]) / 2.0f) : (i64)ts_create[i];
+  if (ts < 0) ts += T;                                       // python indexing
+  const PT* M = pose + 16 * ts;
+  const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float r0 = (float)M[4 * r], r1 = (float)M[4 * r + 1], r2 = (float)M[4 * r + 2], t = (float)M[4 * r + 3];
+    pts[3 * i + r] = ((r0 * x + r1 * y) + r2 * z) + t;       // bmm row, then + translation
+  }
+  // rotmat_to_quat (utils/tools.py:754-773)
+  const PT qw = sqrt((PT)1.0 + M[0] + M[5] + M[10]) / (PT)2.0;
+  const PT qx = (M[9] - M[6]) / ((PT)4.0 * qw);
+  const PT qy = (M[2] - M[8]) / ((PT)4.0 * qw);
+  const PT qz = (M[4] - M[1]) / ((PT)4.0 * qw);
+  // quat_multiply(diff, q) (utils/tools.py:811-829)
+  const PT w2 = (PT)quat[4 * i], x2 = (PT)quat[4 * i + 1], y2 = (PT)quat[4 * i + 2], z2 = (PT)quat[4 * i + 3];
+  quat[4 * i] = (float)(qw * w2 - qx * x2 - qy * y2 - qz * z2);
+  quat[4 * i + 1] = (float)(qw * x2 + qx * w2 + qy * z2 - qz * y2);
+  quat[4 * i + 2] = (float)(qw * y2 - qx * z2 + qy * w2 + qz * x2);
+  quat[4 * i + 3] = (float)(qw * z2 + qx * y2 - qy * x2 + qz * w2);
+}
+
+// recreate_hash (:939-1010): buffer_pt_index[hash(points[value_j])] = value_j for j = 0..M-1, duplicates: the last j
+// wins (the reference's CPU index_put_ outcome), as in upd_commit_kernel / upd_unpack_kernel.
+__global__ __launch_bounds__(256) void rehash_commit_kernel(i64 M, const float* __restrict__ pts,
+                                                            const i64* __restrict__ sample_idx, float res, i64 S,
+                                                            i64* __restrict__ table, i64* __restrict__ slot_of) {
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const i64 v = sample_idx ? sample_idx[j] : j;
+  const i64 slot = hash_slot_of(pts + 3 * v, res, S);
+  slot_of[j] = slot;
+  const i64 packed = (i64)(((unsigned long long)(j + 1) << 32) | (unsigned long long)(uint32_t)v);
+  atomicMax(reinterpret_cast<long long*>(&table[slot]), (long long)packed);
+}
+__global__ __launch_bounds__(256) void rehash_unpack_kernel(i64 M, const i64* __restrict__ slot_of, i64* __restrict__ table) {
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const i64 v = table[slot_of[j]];
+  if ((v >> 32) >= 1) table[slot_of[j]] = (i64)(int32_t)(uint32_t)(v & 0xFFFFFFFFll);
+}
+
 }  // namespace
+
+PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int32_t cur_ts, const int32_t* point_ts_update,
+                                   const float* point_certainties, float diff_travel_dist_local,
+                                   float prune_certainty_thre, uint8_t* prune_mask, void* stream) {
+  PINGS_ARG_CHECK(N >= 0, "negative N");
+  if (N == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(travel_dist && point_ts_update && point_certainties && prune_mask && cur_ts >= 0, "bad argument");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("map_prune_mask", st);
+  prune_mask_kernel<<<blocks_for(N), 256, 0, st>>>(N, travel_dist, cur_ts, point_ts_update, point_certainties,
+                                                   diff_travel_dist_local, prune_certainty_thre, prune_mask);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API int pings_map_adjust(int64_t N, float* neural_points, float* point_orientations, const int32_t* point_ts_create,
+                               const int32_t* point_ts_update, int32_t use_mid_ts, const void* pose_diff,
+                               int32_t pose_is_f64, int64_t num_poses, void* stream) {
+  PINGS_ARG_CHECK(N >= 0 && num_poses > 0, "bad sizes");
+  if (N == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(neural_points && point_orientations && point_ts_create && pose_diff, "null pointer");
+  PINGS_ARG_CHECK(!use_mid_ts || point_ts_update, "use_mid_ts needs point_ts_update");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("map_adjust", st);
+  if (pose_is_f64)
+    adjust_kernel<double><<<blocks_for(N), 256, 0, st>>>(N, neural_points, point_orientations, point_ts_create,
+                                                         point_ts_update, use_mid_ts, (const double*)pose_diff, num_poses);
+  else
+    adjust_kernel<float><<<blocks_for(N), 256, 0, st>>>(N, neural_points, point_orientations, point_ts_create,
+                                                        point_ts_update, use_mid_ts, (const float*)pose_diff, num_poses);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API int pings_map_rehash(const float* neural_points, const int64_t* sample_idx, int64_t M, float resolution,
+                               int64_t buffer_size, int64_t* table, int64_t* slot_scratch, void* stream) {
+  PINGS_ARG_CHECK(M >= 0 && buffer_size > 0 && table && resolution > 0.f, "bad argument");
+  hipStream_t st = pings::as_stream(stream);
+  pings::prof::Scope sc("map_rehash", st);
+  PINGS_HIP_CHECK(hipMemsetAsync(table, 0xFF, sizeof(int64_t) * (size_t)buffer_size, st));   // every slot -1
+  if (M == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(neural_points && slot_scratch && M < ((int64_t)1 << 31), "bad argument");
+  rehash_commit_kernel<<<blocks_for(M), 256, 0, st>>>(M, neural_points, (const i64*)sample_idx, resolution, buffer_size,
+                                                      (i64*)table, (i64*)slot_scratch);
+  PINGS_LAUNCH_CHECK();
+  rehash_unpack_kernel<<<blocks_for(M), 256, 0, st>>>(M, (const i64*)slot_scratch, (i64*)table);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
 
 PINGS_API size_t pings_voxel_downsample_scratch_bytes(int64_t N) { return carve_vds(nullptr, N).total; }
 
 PINGS_API int pings_voxel_downsample(const float* points, int64_t N, float voxel_size, void* scratch,
                                      int64_t* sample_idx, int64_t* count, void* stream) {
+  return pings_voxel_downsample_min_value(points, nullptr, N, voxel_size, scratch, sample_idx, count, stream);
+}
+
+PINGS_API int pings_voxel_downsample_min_value(const float* points, const float* value, int64_t N, float voxel_size,
+                                               void* scratch, int64_t* sample_idx, int64_t* count, void* stream) {
   PINGS_ARG_CHECK(count != nullptr, "null count");
   *count = 0;
   if (N == 0) return PINGS_OK;
@@ -404,10 +528,10 @@ PINGS_API int pings_voxel_downsample(const float* points, int64_t N, float voxel
   VdsScratch s = carve_vds(scratch, N);
   pings::prof::Scope sc("voxel_downsample", st);
   const int nb = (int)std::min<i64>(kBoundBlocks, (N + 255) / 256);
-  vds_bounds_kernel<<<nb, 256, 0, st>>>(points, N, voxel_size, s.partial);
+  vds_bounds_kernel<<<nb, 256, 0, st>>>(points, N, voxel_size, s.partial, value);
   PINGS_LAUNCH_CHECK();
   vds_finish_bounds_kernel<<<1, 1, 0, st>>>(s.partial, nb, voxel_size, s.info);
-  vds_key_kernel<<<blocks_for(N), 256, 0, st>>>(points, N, voxel_size, s.info, s.key, s.val);
+  vds_key_kernel<<<blocks_for(N), 256, 0, st>>>(points, N, voxel_size, s.info, s.key, s.val, value);
   PINGS_LAUNCH_CHECK();
   size_t tb = s.temp_bytes;
   PINGS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(s.temp, tb, s.key, s.key_sorted, s.val, s.val_sorted, (int)N, 0,

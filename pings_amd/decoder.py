@@ -42,6 +42,30 @@ def mlp_batch(decoder, features: torch.Tensor) -> torch.Tensor:
     return orig(decoder, features) if orig is not None else decoder.mlp_batch(features)
 
 
+def mlp(decoder, features: torch.Tensor) -> torch.Tensor:
+    """`Decoder.mlp(features)` (model/decoder.py:62-82) for [N, IN] or [N, K, IN] inputs through the fused MFMA kernels.
+    Every head of the class goes through it — `sdf` (:100-104), `occupancy` (:115-117), `sem_label_prob` / `sem_label`
+    (:119-126) and `regress_color` (:133-134; the mapper's colour-on SDF loop, utils/mapper.py:866-870, and the mesher's
+    colour head) — so rebinding this one method moves them all off the torch GEMMs.  Decoder shapes the kernels do not
+    cover (more than one hidden level, leaky ReLU, no bias, widths outside `mlp.supported`) run the module's own torch
+    layers on the device."""
+    if not features.is_cuda:
+        from . import _lib
+
+        raise _lib.PingsHipError("decoder.mlp runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+    if _supported(decoder) and features.numel() > 0:
+        from . import mlp as _mlp
+
+        l0, lo = decoder.layers[0], decoder.lout
+        y = _mlp.fused_mlp(features.reshape(-1, features.shape[-1]), l0.weight, l0.bias, lo.weight, lo.bias)
+        return y.view(*features.shape[:-1], y.shape[-1])
+    orig = getattr(type(decoder), "_pings_mlp_torch", None)     # set by install(): the class's own method
+    if orig is None:
+        raise NotImplementedError("decoder.mlp: this decoder shape has no fused kernel and the class's own `mlp` was "
+                                  "not kept (call pings_amd.decoder.install(Decoder))")
+    return orig(decoder, features)
+
+
 def sdf(decoder, features: torch.Tensor) -> torch.Tensor:
     """`Decoder.sdf(features)` (model/decoder.py:100-104): `mlp(features).squeeze(1) * sdf_scale` for [N, IN] or
     [N, K, IN] inputs — the decoder call of the mapper's training / inference loops (utils/mapper.py:537,574,858,1508,
@@ -57,12 +81,16 @@ def sdf(decoder, features: torch.Tensor) -> torch.Tensor:
         l0, lo = decoder.layers[0], decoder.lout
         y = _mlp.fused_mlp(features.reshape(-1, features.shape[-1]), l0.weight, l0.bias, lo.weight, lo.bias)
         return y.view(*features.shape[:-1], y.shape[-1]).squeeze(1) * decoder.sdf_scale
-    return decoder.mlp(features).squeeze(1) * decoder.sdf_scale
+    orig = getattr(type(decoder), "_pings_mlp_torch", None)
+    return (orig(decoder, features) if orig is not None else decoder.mlp(features)).squeeze(1) * decoder.sdf_scale
 
 
 def install(decoder_cls) -> None:
-    """`Decoder.sdf` and `Decoder.mlp_batch` of the reference class through the fused kernels (the parameters stay
-    the module's own)."""
+    """`Decoder.mlp` — and with it `sdf`, `occupancy`, `sem_label_prob`, `sem_label`, `regress_color` — and
+    `Decoder.mlp_batch` of the reference class through the fused kernels (the parameters stay the module's own)."""
+    if hasattr(decoder_cls, "mlp") and not hasattr(decoder_cls, "_pings_mlp_torch"):
+        decoder_cls._pings_mlp_torch = decoder_cls.mlp
+        decoder_cls.mlp = mlp
     decoder_cls.sdf = sdf
     if hasattr(decoder_cls, "mlp_batch") and not hasattr(decoder_cls, "_pings_mlp_batch_torch"):
         decoder_cls._pings_mlp_batch_torch = decoder_cls.mlp_batch

@@ -47,6 +47,14 @@ def _declare(L):
     L.pings_map_reset_local.restype = C.c_int
     L.pings_map_reset_local.argtypes = [i64, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, f32, f32,
                                         vp, vp, vp, vp, vp, C.POINTER(i64), vp]
+    L.pings_voxel_downsample_min_value.restype = C.c_int
+    L.pings_voxel_downsample_min_value.argtypes = [vp, vp, i64, f32, vp, vp, C.POINTER(i64), vp]
+    L.pings_map_prune_mask.restype = C.c_int
+    L.pings_map_prune_mask.argtypes = [i64, vp, i32, vp, vp, f32, f32, vp, vp]
+    L.pings_map_adjust.restype = C.c_int
+    L.pings_map_adjust.argtypes = [i64, vp, vp, vp, vp, i32, vp, i32, i64, vp]
+    L.pings_map_rehash.restype = C.c_int
+    L.pings_map_rehash.argtypes = [vp, vp, i64, f32, i64, vp, vp, vp]
     L.pings_gather_rows.restype = C.c_int
     L.pings_gather_rows.argtypes = [vp, i64, vp, i64, vp, vp]
     L.pings_scatter_rows.restype = C.c_int
@@ -65,8 +73,9 @@ def _need_device(t: torch.Tensor, what: str):
         raise _lib.PingsHipError(f"{what} runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
 
 
-def voxel_down_sample(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
-    """`voxel_down_sample_torch(points, voxel_size)` (utils/tools.py:924-967): int64 indices, one per voxel."""
+def voxel_down_sample(points: torch.Tensor, voxel_size: float, value: torch.Tensor = None) -> torch.Tensor:
+    """`voxel_down_sample_torch(points, voxel_size)` (utils/tools.py:924-967) or, with `value`,
+    `voxel_down_sample_min_value_torch(points, voxel_size, value)` (:970-1009): int64 indices, one per voxel."""
     _need_device(points, "voxel_down_sample")
     L = _L()
     pts = points.detach().to(torch.float32).contiguous()
@@ -74,9 +83,11 @@ def voxel_down_sample(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
     dev = pts.device
     out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     scratch = torch.empty(L.pings_voxel_downsample_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    val = value.detach().to(device=dev, dtype=torch.float32).contiguous() if value is not None else None
     cnt = C.c_int64(0)
-    _lib.check(L.pings_voxel_downsample(_lib.ptr(pts), n, float(voxel_size), _lib.ptr(scratch), _lib.ptr(out),
-                                        C.byref(cnt), _lib.stream_ptr(dev)), "pings_voxel_downsample")
+    _lib.check(L.pings_voxel_downsample_min_value(_lib.ptr(pts), _lib.ptr(val), n, float(voxel_size), _lib.ptr(scratch),
+                                                  _lib.ptr(out), C.byref(cnt), _lib.stream_ptr(dev)),
+               "pings_voxel_downsample")
     return out[:cnt.value]
 
 
@@ -259,6 +270,111 @@ def assign_local_to_global(m):
         _scatter(L, m.local_color_features.data, lidx, nl + 1, m.color_features)
 
 
+# ------------------------------------------------------------------ loop closure (model/neural_gaussians.py:871-1010)
+def _table_changed(m):
+    m._pings_table_gen = getattr(m, "_pings_table_gen", 0) + 1
+    m.__dict__.pop("_pings_compact", None)
+    m.__dict__.pop("_pings_blocks", None)
+
+
+def _compact_rows(m, L, rows: torch.Tensor):
+    """Every per-point tensor reduced to `rows` (int64, ascending or in merge order) and the feature tables to
+    `rows` + the padding row (:889-907, :976-993)."""
+    n_old = int(m.neural_points.shape[0])
+    k = int(rows.shape[0])
+    for name in _ROW_ATTRS:
+        t = getattr(m, name, None)
+        if t is None:
+            continue
+        setattr(m, name, _gather(L, t, rows, k))
+    rows_pad = torch.cat((rows, torch.tensor([n_old], dtype=torch.int64, device=rows.device)))
+    m.geo_features = _gather(L, m.geo_features, rows_pad, k + 1)
+    if getattr(m, "color_features", None) is not None:
+        m.color_features = _gather(L, m.color_features, rows_pad, k + 1)
+
+
+def prune_map(m, prune_certainty_thre, min_prune_count=500) -> bool:
+    """`NeuralPoints.prune_map` (model/neural_gaussians.py:871-909): drops the inactive, uncertain neural points when
+    there are more than `min_prune_count` of them; the caller recreates the hash and the local map afterwards."""
+    _need_device(m.neural_points, "NeuralPoints.prune_map")
+    L = _L()
+    dev = m.neural_points.device
+    n = int(m.neural_points.shape[0])
+    travel = m.travel_dist.detach().to(device=dev, dtype=torch.float32).contiguous()
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(L.pings_map_prune_mask(n, _lib.ptr(travel), int(m.cur_ts), _lib.ptr(m.point_ts_update.contiguous()),
+                                      _lib.ptr(m.point_certainties.contiguous()), float(m.diff_travel_dist_local),
+                                      float(prune_certainty_thre), _lib.ptr(mask), _lib.stream_ptr(dev)),
+               "pings_map_prune_mask")
+    _lib.note_sync("prune_count")                      # reference: `.item()` at :882
+    prune_count = int(mask.sum().item())
+    if prune_count > min_prune_count:
+        if not getattr(m, "silence", True):
+            print("# Prune neural points: ", prune_count)
+        keep = torch.nonzero_static(mask == 0, size=n - prune_count).view(-1)
+        _compact_rows(m, L, keep)
+        return True
+    return False
+
+
+def adjust_map(m, pose_diff_torch: torch.Tensor) -> None:
+    """`NeuralPoints.adjust_map` (model/neural_gaussians.py:911-937): after loop closure / PGO every neural point is
+    moved by the pose correction of its timestamp, in place."""
+    _need_device(m.neural_points, "NeuralPoints.adjust_map")
+    L = _L()
+    dev = m.neural_points.device
+    m.after_pgo = True
+    cfg = getattr(m, "config", m)
+    pose = pose_diff_torch.detach().to(dev)
+    f64 = pose.dtype == torch.float64
+    pose = pose.to(torch.float64 if f64 else torch.float32).contiguous()
+    pts, quat = m.neural_points, m.point_orientations
+    if not pts.is_contiguous() or not quat.is_contiguous() or quat.dtype != torch.float32:
+        pts, quat = pts.contiguous(), quat.to(torch.float32).contiguous()
+        m.neural_points, m.point_orientations = pts, quat
+    n = int(pts.shape[0])
+    _lib.check(L.pings_map_adjust(n, _lib.ptr(pts), _lib.ptr(quat), _lib.ptr(m.point_ts_create.contiguous()),
+                                  _lib.ptr(m.point_ts_update.contiguous()), int(bool(getattr(cfg, "use_mid_ts", False))),
+                                  _lib.ptr(pose), int(f64), int(pose.shape[0]), _lib.stream_ptr(dev)), "pings_map_adjust")
+    _table_changed(m)                                  # positions moved: the table and every index of it are stale
+
+
+def recreate_hash(m, sensor_position: torch.Tensor, sensor_orientation: torch.Tensor = None, kept_points: bool = True,
+                  with_ts: bool = True, cur_ts=0) -> None:
+    """`NeuralPoints.recreate_hash` (model/neural_gaussians.py:939-1010): one representative per voxel (closest in time
+    to `cur_ts`, or the most certain), the table rebuilt from them; with `kept_points=False` the map itself is reduced
+    to the representatives."""
+    _need_device(m.neural_points, "NeuralPoints.recreate_hash")
+    L = _L()
+    dev = m.neural_points.device
+    cfg = getattr(m, "config", m)
+    res = float(m.resolution)
+    if with_ts:
+        if bool(getattr(cfg, "use_mid_ts", False)):
+            ts_used = ((m.point_ts_create + m.point_ts_update) / 2).int()
+        else:
+            ts_used = m.point_ts_create
+        value = torch.abs(ts_used - cur_ts).float()
+    else:
+        value = m.point_certainties.max() - m.point_certainties
+    sample_idx = voxel_down_sample(m.neural_points, res, value)
+    table = m.buffer_pt_index
+    if table.dtype != torch.int64 or not table.is_contiguous():
+        raise TypeError("buffer_pt_index must be a contiguous int64 tensor (neural_gaussians.py:46,86)")
+    M = int(sample_idx.shape[0])
+    if not kept_points:
+        if not getattr(m, "silence", True):
+            print("Filter duplicated neural points")
+        _compact_rows(m, L, sample_idx)
+        sample_idx = None
+    slots = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
+    _lib.check(L.pings_map_rehash(_lib.ptr(m.neural_points.contiguous()), _lib.ptr(sample_idx), M, res, int(m.buffer_size),
+                                  _lib.ptr(table), _lib.ptr(slots), _lib.stream_ptr(dev)), "pings_map_rehash")
+    _table_changed(m)
+    if sensor_position is not None:
+        reset_local_map(m, sensor_position, sensor_orientation, cur_ts)
+
+
 def new_map(buffer_size: int, geo_dim: int, color_dim: int, resolution: float, temporal_local_map_on=True,
             use_mid_ts=False, range_filter_2d=False, local_map_radius=5.0, sorrounding_map_radius=7.0,
             diff_travel_dist_local=2.0, color_on=True, device="cuda") -> SimpleNamespace:
@@ -292,3 +408,6 @@ def install(neural_points_cls) -> None:
     neural_points_cls.update = update
     neural_points_cls.reset_local_map = reset_local_map
     neural_points_cls.assign_local_to_global = assign_local_to_global
+    neural_points_cls.prune_map = prune_map
+    neural_points_cls.adjust_map = adjust_map
+    neural_points_cls.recreate_hash = recreate_hash

@@ -79,6 +79,82 @@ def test_global2local_quirk_is_one_not_minus_one(golden_dir):
     assert g2l[-1] == -1 and (g2l[:-1][~lm[:-1]] == 1).all()      # torch.full_like(bool, -1).long()
 
 
+# ------------------------------------------------------------------ loop closure (G12)
+_SNAP = ("neural_points", "point_orientations", "point_ts_create", "point_ts_update", "point_certainties", "point_colors",
+         "valid_color_mask", "valid_gs_mask", "free_gs_mask", "geo_features", "color_features")
+
+
+def _check_snap(m, cst, tag, float_tol=None):
+    for k in _SNAP:
+        a, b = getattr(m, k).detach().cpu().numpy(), cst[f"{tag}_{k}"]
+        assert a.shape == b.shape and a.dtype == b.dtype, (tag, k, a.shape, b.shape, a.dtype, b.dtype)
+        if float_tol is not None and k in ("neural_points", "point_orientations"):
+            assert np.abs(a - b).max() <= float_tol * max(1.0, np.abs(b).max()), (tag, k, np.abs(a - b).max())
+        else:
+            assert np.array_equal(a, b), (tag, k)
+    tab = m.buffer_pt_index
+    nz = torch.nonzero(tab >= 0).flatten()
+    _eq(nz, cst[f"{tag}_table_slots"], tag + "_table_slots")
+    _eq(tab[nz], cst[f"{tag}_table_vals"], tag + "_table_vals")
+
+
+def _run_closure(st, cst, mod, device):
+    """prune_map -> adjust_map -> recreate_hash(kept, by timestamp) -> recreate_hash(merged, by certainty) on the map the
+    G8 frames built, every tensor against the reference's own `NeuralPoints` (oracle/make_golden.py:make_map_closure).
+    Indices, masks, timestamps, features and table entries exact; the moved positions / rotated orientations to 2e-6
+    (a 3-term fp32 dot product and a float64 quaternion product, association free)."""
+    T = lambda k: torch.from_numpy(cst[k]).to(device)
+    m = _run_frames(st, mod, device)
+    m.cur_ts = int(st["frames"]) - 1
+    m.point_certainties = T("certainties_in")
+    pruned = mod.prune_map(m, float(cst["prune_thre"]), int(cst["min_prune_count"]))
+    assert pruned == bool(cst["pruned"])
+    _check_snap(m, cst, "prune")
+    mod.adjust_map(m, T("pose_diff"))
+    assert m.after_pgo is True
+    _check_snap(m, cst, "adjust", float_tol=2e-6)
+    # the voxel representatives depend on floor(p / res) of the MOVED points: continue from the reference's positions so
+    # that a last-bit difference of the transform cannot move a point across a voxel boundary (checked to 2e-6 above)
+    m.neural_points, m.point_orientations = T("adjust_neural_points"), T("adjust_point_orientations")
+    cur_ts = int(st["frames"]) - 1
+    ts_used = ((m.point_ts_create + m.point_ts_update) / 2).int() if bool(st["use_mid_ts"]) else m.point_ts_create
+    sidx = mod.voxel_down_sample_min_value(m.neural_points, m.resolution, torch.abs(ts_used - cur_ts).float())
+    _eq(sidx, cst["keep_sample_idx"], "keep_sample_idx")
+    mod.recreate_hash(m, T("sensor"), None, True, True, cur_ts)
+    _check_snap(m, cst, "keep")
+    _eq(m.local_mask, cst["keep_local_mask"], "keep_local_mask")
+    _eq(m.global2local, cst["keep_global2local"], "keep_global2local")
+    sidx = mod.voxel_down_sample_min_value(m.neural_points, m.resolution, m.point_certainties.max() - m.point_certainties)
+    _eq(sidx, cst["merge_sample_idx"], "merge_sample_idx")
+    mod.recreate_hash(m, T("sensor"), None, False, False, cur_ts)
+    _check_snap(m, cst, "merge")
+    _eq(m.local_mask, cst["merge_local_mask"], "merge_local_mask")
+    _eq(m.global2local, cst["merge_global2local"], "merge_global2local")
+    _eq(m.local_geo_features, cst["merge_local_geo_features"], "merge_local_geo_features")
+    return m
+
+
+class _OracleClosure:
+    """oracle/map_cpu.py with the call shapes `_run_closure` uses."""
+
+    def __getattr__(self, k):
+        return getattr(M, k)
+
+    @staticmethod
+    def recreate_hash(m, sensor, orient, kept, with_ts, cur_ts):
+        M.recreate_hash(m, sensor, orient, kept, with_ts, cur_ts)
+
+
+def _load_closure(golden_dir, name):
+    z = np.load(golden_dir / f"mapclosure_{name}.npz")
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_map_closure_oracle_matches_reference_golden_cpu(golden_dir, name):
+    _run_closure(_load(golden_dir, name), _load_closure(golden_dir, name), _OracleClosure(), "cpu")
+
+
 class _HipAdapter:
     """pings_amd.neural_map with the oracle's call shapes."""
 
@@ -96,6 +172,27 @@ class _HipAdapter:
 
     def reset_local_map(self, m, sensor, ts):
         self.NM.reset_local_map(m, sensor, None, ts)
+
+    def prune_map(self, m, thre, min_count):
+        return self.NM.prune_map(m, thre, min_count)
+
+    def adjust_map(self, m, pose):
+        self.NM.adjust_map(m, pose)
+
+    def voxel_down_sample_min_value(self, pts, res, value):
+        return self.NM.voxel_down_sample(pts, res, value)
+
+    def recreate_hash(self, m, sensor, orient, kept, with_ts, cur_ts):
+        self.NM.recreate_hash(m, sensor, orient, kept, with_ts, cur_ts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_map_closure_hip_matches_reference_golden(golden_dir, name):
+    """`prune_map` / `adjust_map` / `recreate_hash` (model/neural_gaussians.py:871-1010) on the device against the G12
+    vectors, and the query path sees the rebuilt table (the cell-block index is invalidated)."""
+    m = _run_closure(_load(golden_dir, name), _load_closure(golden_dir, name), _HipAdapter(), "cuda")
+    assert "_pings_blocks" not in m.__dict__ and "_pings_compact" not in m.__dict__
 
 
 @pytest.mark.gpu
