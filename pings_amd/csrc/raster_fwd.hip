@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t I, const KeyT*
   if (i == I - 1 || key[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
-#ifdef PINGS_BLEND_STATS  // diagnostic build only (scratch/): loop-efficiency counters of blend_fwd_kernel
+#ifdef PINGS_BLEND_STATS  // diagnostic build only: loop-efficiency counters of blend_fwd_kernel
 __device__ unsigned long long g_blend_stats[8];
 #endif
 

@@ -1,10 +1,10 @@
 #!/bin/bash
-# One GPU-box pass of round 2: usage (repo root on the box): bash scratch/gpu_round2.sh <tag> <part>
+# One GPU-box pass of round 2: usage (repo root on the box): bash tools/gpu_round.sh <tag> <part>
 # part 1: tests + smoke + bench;  part 2: rocprofv3 kernel stats + PMC passes + 2-rank rehearsal
 set -o pipefail
 tag=${1:-x}; part=${2:-1}
 R=$PWD
-O=$R/gpurun_out/r02$tag
+O=$R/gpurun_out/r03$tag
 mkdir -p $O
 export TMPDIR=/tmp
 if [ "$part" = "1" ]; then
@@ -22,7 +22,7 @@ else
   for cfg in "1000000 131072" "1000000 16384" "200000 131072" "5000000 131072"; do
     set -- $cfg
     for ctr in FETCH_SIZE WRITE_SIZE; do
-      timeout -k 10 150 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/sdf_${1}_${2}_$ctr -o p -- python3 $R/scratch/sdf_pmc.py $1 $2 > $O/sdf_pmc.log 2>&1; echo "sdf pmc $1 $2 $ctr rc=$?"
+      timeout -k 10 150 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/sdf_${1}_${2}_$ctr -o p -- python3 $R/tools/sdf_pmc.py $1 $2 > $O/sdf_pmc.log 2>&1; echo "sdf pmc $1 $2 $ctr rc=$?"
     done
   done
   cd $R

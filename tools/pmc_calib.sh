@@ -1,9 +1,9 @@
 #!/bin/bash
-# PMC calibration + a fresh default bench line (repo root on the box): bash scratch/gpu_calib.sh <tag>
+# PMC calibration + a fresh default bench line (repo root on the box): bash tools/pmc_calib.sh <tag>
 set -o pipefail
 tag=${1:-x}
 R=$PWD
-O=$R/gpurun_out/r02$tag
+O=$R/gpurun_out/r03$tag
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
