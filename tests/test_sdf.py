@@ -594,7 +594,8 @@ def test_fused_numerical_gradient_equals_the_reference_op_sequence(golden_dir, n
     # agrees to fp32 rounding, which the difference quotient (/ eps) amplifies
     assert rel_err(g_f, g_c) <= 1e-4, rel_err(g_f, g_c)
     for a, b in zip(d_f, d_c):
-        assert rel_err(a, b) <= 1e-4, rel_err(a, b)
+        # (the output bias cancels in a difference quotient: its gradient is an fp32 sum of +v and -v terms, ~1e-5)
+        assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1.0), (a - b).abs().max().item()
     with torch.no_grad():
         g_n = mapper_ops.get_numerical_gradient(m, xq, mapper_ops.sdf(m, xq)[0], eps=eps, two_side=two_side)
     assert torch.equal(g_n, g_f.detach())
