@@ -935,7 +935,8 @@ def main():
     # 40-300 us per backward() depending on the box (measured: a two-operator graph 40 vs 73 us, the fused SDF step 178
     # vs 463 us on two boxes of this pool), which is the whole budget of a 0.16 ms training step.  One line in the
     # training script; no kernel, result or launch order changes.
-    torch.autograd.set_multithreading_enabled(False)
+    if os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") != "1":      # A/B switch: 1 = torch's default worker thread
+        torch.autograd.set_multithreading_enabled(False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1193,7 +1194,8 @@ def main():
     # 40-300 us per backward() depending on the box (measured: a two-operator graph 40 vs 73 us, the fused SDF step 178
     # vs 463 us on two boxes of this pool), which is the whole budget of a 0.16 ms training step.  One line in the
     # training script; no kernel, result or launch order changes.
-    torch.autograd.set_multithreading_enabled(False)
+    if os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") != "1":      # A/B switch: 1 = torch's default worker thread
+        torch.autograd.set_multithreading_enabled(False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

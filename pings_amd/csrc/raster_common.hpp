@@ -71,6 +71,8 @@ struct FrameSummary {   // the record of a frame's one host read-back (frame_sum
   uint32_t total, overflow;
   unsigned long long stats[3];
   int32_t aux[8];
+  uint32_t seq;   // written last (system-scope release): the host polls it instead of blocking in the runtime
+  uint32_t pad;
 };
 
 struct GeomState {
