@@ -1,4 +1,5 @@
 // General C-ABI entry points: version + thread-local error string.
+#include <chrono>
 #include <cstdarg>
 #include <cstring>
 #include <map>
@@ -60,6 +61,60 @@ void end(hipStream_t st) {
   g_open_a = nullptr;
 }
 }  // namespace prof
+}  // namespace pings
+
+// ---------------------------------------------------------------- polled read-back (common.hpp: host_read_words)
+namespace pings {
+namespace {
+struct ReadRecord {
+  uint32_t w[8];
+  uint32_t seq;
+  uint32_t pad[7];
+};
+struct ReadPtrs {
+  const uint32_t* p[8];
+};
+__global__ __launch_bounds__(64) void read_words_kernel(ReadPtrs ptrs, int n, ReadRecord* out, uint32_t seq) {
+  const int lane = threadIdx.x;
+  if (lane < 8) out->w[lane] = (lane < n && ptrs.p[lane]) ? *ptrs.p[lane] : 0u;
+  __threadfence_system();
+  __syncthreads();
+  if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+int host_read_words(const uint32_t* const* dev_words, int n, uint32_t* out, hipStream_t st) {
+  PINGS_ARG_CHECK(n >= 1 && n <= 8 && dev_words && out, "1..8 words");
+  static thread_local ReadRecord* rec = nullptr;
+  static thread_local ReadRecord* rec_dev = nullptr;
+  static thread_local uint32_t counter = 0;
+  if (!rec) {
+    PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&rec), sizeof(ReadRecord), hipHostMallocMapped));
+    PINGS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&rec_dev), rec, 0));
+    rec->seq = 0;
+  }
+  ReadPtrs ptrs;
+  for (int i = 0; i < 8; ++i) ptrs.p[i] = i < n ? dev_words[i] : nullptr;
+  const uint32_t seq = ++counter ? counter : ++counter;
+  hipLaunchKernelGGL(read_words_kernel, dim3(1), dim3(64), 0, st, ptrs, n, rec_dev, seq);
+  PINGS_LAUNCH_CHECK();
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipErrorNotReady) (void)hipGetLastError();
+      else if (q != hipSuccess) PINGS_HIP_CHECK(q);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+        PINGS_HIP_CHECK(hipStreamSynchronize(st));
+        PINGS_ARG_CHECK(__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) == seq, "read-back never arrived");
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  for (int i = 0; i < n; ++i) out[i] = rec->w[i];
+  return PINGS_OK;
+}
 }  // namespace pings
 
 PINGS_API int pings_prof_enable(int on) {

@@ -17,6 +17,13 @@ __host__ __device__ constexpr T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Stream-ordered read of up to 8 device words (32 bit each) into host memory WITHOUT a blocking wait inside the HIP
+// runtime: one wave copies the words into pinned, device-mapped host memory behind everything already queued on `st` and
+// the host polls a sequence number (abi.hip).  A blocking hipStreamSynchronize wakes through an interrupt, which on one
+// box of the pool arrived only with a 60 Hz tick (16 ms per wait); polling does not depend on it and costs a few
+// microseconds on every box.  Returns a PINGS status.
+int host_read_words(const uint32_t* const* dev_words, int n, uint32_t* out, hipStream_t st);
+
 // Optional per-stage HIP-event timing (off by default; bench.py turns it on to get the
 // per-kernel durations its roofline figures are computed from).
 namespace prof {

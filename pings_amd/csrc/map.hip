@@ -541,10 +541,10 @@ PINGS_API int pings_voxel_downsample_min_value(const float* points, const float*
                                                     hipcub::Min(), (int)N, st));
   vds_unpack_kernel<<<blocks_for(N), 256, 0, st>>>(s.agg, s.nruns, reinterpret_cast<i64*>(sample_idx));
   PINGS_LAUNCH_CHECK();
-  int runs = 0;
-  PINGS_HIP_CHECK(hipMemcpyAsync(&runs, s.nruns, sizeof(int), hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipStreamSynchronize(st));
-  *count = runs;
+  uint32_t runs = 0;
+  const uint32_t* src[1] = {reinterpret_cast<const uint32_t*>(s.nruns)};
+  if (int e = pings::host_read_words(src, 1, &runs, st)) return e;
+  *count = (int64_t)(int)runs;
   return PINGS_OK;
 }
 
@@ -604,11 +604,11 @@ PINGS_API int pings_map_update(const float* sample_points, const float* sample_c
   upd_commit_kernel<<<nb, 256, 0, st>>>(a);
   upd_unpack_kernel<<<nb, 256, 0, st>>>(a);
   PINGS_LAUNCH_CHECK();
-  int32_t last[2] = {0, 0};
-  PINGS_HIP_CHECK(hipMemcpyAsync(&last[0], a.pos + (M - 1), 4, hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipMemcpyAsync(&last[1], a.flag + (M - 1), 4, hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipStreamSynchronize(st));
-  *num_new = (int64_t)last[0] + last[1];
+  uint32_t last[2] = {0, 0};
+  const uint32_t* src[2] = {reinterpret_cast<const uint32_t*>(a.pos + (M - 1)),
+                            reinterpret_cast<const uint32_t*>(a.flag + (M - 1))};
+  if (int e = pings::host_read_words(src, 2, last, st)) return e;
+  *num_new = (int64_t)(int32_t)last[0] + (int32_t)last[1];
   return PINGS_OK;
 }
 
@@ -668,10 +668,11 @@ PINGS_API int pings_map_reset_local(int64_t num_points, const float* neural_poin
     PINGS_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, tb, a.lflag, a.lpos, (int)num_points, st));
   rst_index_kernel<<<blocks_for(num_points + 1), 256, 0, st>>>(a);
   PINGS_LAUNCH_CHECK();
-  i64 nl = 0;
-  PINGS_HIP_CHECK(hipMemcpyAsync(&nl, a.nlocal_dev, sizeof(i64), hipMemcpyDeviceToHost, st));
-  PINGS_HIP_CHECK(hipStreamSynchronize(st));
-  *num_local = (int64_t)nl;
+  uint32_t nl[2] = {0, 0};
+  const uint32_t* src[2] = {reinterpret_cast<const uint32_t*>(a.nlocal_dev),
+                            reinterpret_cast<const uint32_t*>(a.nlocal_dev) + 1};
+  if (int e = pings::host_read_words(src, 2, nl, st)) return e;
+  *num_local = (int64_t)(((unsigned long long)nl[1] << 32) | nl[0]);
   return PINGS_OK;
 }
 
