@@ -1048,261 +1048,6 @@ def main():
     def step():
         for p_ in params + [theta, rho]:
             p_.grad = None
-        img, nrm, dep, alp, radii, contrib = rast(means3D=params[0], means2D=torch.zeros_like(params[0]),
-                                                  colors_precomp=params[1], opacities=params[2], scales=params[3],
-                                                  rotations=params[4], theta=theta, rho=rho)
-        torch.autograd.backward([img, nrm, dep, alp], ups)
-        return radii
-
-    radii = step()
-    t = _timeit(step, steps, warmup)
-    pr = _prof_run(L, step, max(2, steps // 4))
-    with torch.no_grad():
-        fs, _, _ = hr._forward(rast._prepared(), *[p_.detach() for p_ in params])
-        _, rg_, _, nc_ = hr.debug_lists(fs)
-        lens = rg_[:, 1] - rg_[:, 0]
-    P = params[0].shape[0]
-    return {"workload": name, "gaussians": P, "width": W, "height": H, "ms_per_step": round(t * 1e3, 4),
-            "Mpix_s": round(W * H / t / 1e6, 1), "instances": int(fs.I), "visible_gaussians": int((radii > 0).sum().item()),
-            "mean_list_len_per_tile": round(float(lens.float().mean()), 1), "longest_list": int(lens.max()),
-            "max_contributors_per_pixel": int(nc_.max()),
-            "kernels_ms": {k: round(v, 4) for k, v in pr.items()}}
-
-
-class _BenchDecoder(torch.nn.Module):
-    """Duck-typed `Decoder` (model/decoder.py:15-98): one hidden level, ReLU, bias."""
-
-    def __init__(self, fin, hidden, out_dim, K, gen, device):
-        super().__init__()
-        self.layers = torch.nn.ModuleList([torch.nn.Linear(fin, hidden)])
-        self.lout = torch.nn.Linear(hidden, out_dim * K)
-        with torch.no_grad():
-            self.layers[0].weight.copy_(torch.randn(hidden, fin, generator=gen) / fin ** 0.5)
-            self.layers[0].bias.copy_(0.1 * torch.randn(hidden, generator=gen))
-            self.lout.weight.copy_(torch.randn(out_dim * K, hidden, generator=gen) / hidden ** 0.5 * 0.5)
-            self.lout.bias.copy_(0.1 * torch.randn(out_dim * K, generator=gen))
-        self.out_k, self.mlp_out_dim, self.use_leaky_relu = K, out_dim * K, False
-        self.to(device)
-
-
-def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8):
-    """One iteration of the Gaussian-mapping loop body as an unmodified mapper reaches it (utils/mapper.py:1126-1295,
-    :1581): `render()` (markVisible -> spawn + the five decoders -> rasterise -> depth2normal -> exposure), the
-    photometric loss block, fused-SSIM, backward to the neural-point features, the decoders, exposure and pose.
-    The rasteriser object is constructed inside render() on every call, as the reference does (:149-201).
-    n_points neural points on a street-like surface, K Gaussians each (F_g 32, F_c 16, hidden 128, pings.py:156-160)."""
-    from pings_amd import _lib
-    from pings_amd.camera import Camera
-    from pings_amd.image_losses import image_losses
-    from pings_amd.renderer import render
-    from pings_amd.ssim import fused_ssim
-
-    L = _lib_handle()
-    sys.path.insert(0, str(ROOT / "tests"))
-    from scenes import street_scene
-
-    g = torch.Generator().manual_seed(8)
-    pos, base_col, _, _, _ = street_scene(n_points, device=dev, seed=2)
-    n = pos.shape[0]
-    quat = torch.tensor([1.0, 0, 0, 0], device=dev).repeat(n, 1)
-    geo = (0.3 * torch.randn(n + 1, 32, generator=g)).to(dev).requires_grad_(True)
-    cfe = (0.3 * torch.randn(n + 1, 16, generator=g)).to(dev).requires_grad_(True)
-    decs = {"gauss_xyz": _BenchDecoder(32, 128, 3, K, g, dev), "gauss_rot": _BenchDecoder(32, 128, 4, K, g, dev),
-            "gauss_scale": _BenchDecoder(32, 128, 3, K, g, dev), "gauss_alpha": _BenchDecoder(32, 128, 1, K, g, dev),
-            "gauss_color": _BenchDecoder(16 + 3, 128, 3, K, g, dev)}
-    data = {"position": pos, "orientation": quat, "color": base_col, "geo_feature": geo, "color_feature": cfe,
-            "resolution": 0.2, "free_mask": torch.zeros(n, dtype=torch.bool, device=dev),
-            "valid_mask": torch.ones(n, dtype=torch.bool, device=dev)}
-    fx = 1000.0 * W / 1920.0
-    cam = Camera(W, H, fx, fx, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, torch.eye(4, dtype=torch.float64), device=dev)
-    bg = torch.ones(3, device=dev)
-    gd = torch.Generator(device=dev).manual_seed(9)
-    gt_rgb = torch.rand(3, H, W, generator=gd, device=dev)
-    gt_depth = 2.0 + 40.0 * torch.rand(1, H, W, generator=gd, device=dev)
-    sky = torch.rand(1, H, W, generator=gd, device=dev) < 0.1
-    leaves = [geo, cfe] + [p for d in decs.values() for p in d.parameters()] + \
-             [cam.exposure_mat, cam.exposure_offset, cam.cam_rot_delta, cam.cam_trans_delta]
-    info = {}
-
-    def step():
-        for p_ in leaves:
-            p_.grad = None
-        pkg = render(cam, None, data, decs, None, bg, view_concat_on=True, learn_color_residual=True, d2n_on=True,
-                     gs_type="gaussian_surfel")
-        il = image_losses(pkg["render"], gt_rgb, pkg["surf_depth"], gt_depth, pkg["rend_alpha"], pkg["rend_normal"],
-                          pkg["surf_normal"], sky, depth_min=0.3, depth_max=80.0, depth_min_accu_alpha=0.4)
-        ssim = fused_ssim(pkg["render"].unsqueeze(0), gt_rgb.unsqueeze(0))
-        loss = 0.8 * il.rgb_l1 + 0.2 * (1.0 - ssim) + 0.5 * il.depth_l1 + 0.05 * il.normal_depth_consist + 0.1 * il.sky
-        loss.backward()
-        info["gaussians"] = int(pkg["gaussian_xyz"].shape[0])
-        info["visible_ratio"] = pkg["visible_neural_point_ratio"]
-
-    step()
-    _lib.sync_counts(reset=True)
-    step()
-    syncs = _lib.sync_counts(reset=True)
-    t = _timeit(step, steps, warmup)
-    pr = _prof_run(L, step, max(2, steps // 4))
-    groups = {"decoders_fwd": ("mlp_fwd",), "decoders_bwd": ("mlp_bwd",), "ssim": ("ssim_fwd", "ssim_bwd"),
-              "image_losses": ("image_losses_fwd", "image_losses_bwd")}
-    return {"width": W, "height": H, "neural_points": n, "gaussians_rasterised": info["gaussians"],
-            "visible_neural_point_ratio": round(float(info["visible_ratio"]), 3), "ms_per_step": round(t * 1e3, 4),
-            "Mpix_s": round(W * H / t / 1e6, 1), "host_syncs_per_render": syncs,
-            "host_syncs_total": int(sum(syncs.values())),
-            "stage_ms": {k: round(v, 4) for k, v in sorted(pr.items(), key=lambda kv: -kv[1])},
-            "stage_ms_sum": round(sum(pr.values()), 4),
-            "grouped_ms": {k: round(sum(pr.get(n_, 0.0) for n_ in v), 4) for k, v in groups.items()}}
-
-
-def cpu_baseline_sdf(npm, dec, B=131072, reps=8, weighted_first=False, label="1M-point map"):
-    """The reference's PyTorch-CPU SDF path (oracle port: same torch op sequence) on the host cores, one process,
-    same map and queries as the GPU run (tensors copied to the host); the torch thread count is the fastest of
-    8..128 on this host (the survey container's 8 vCPUs gave 0.26-0.36 Msamples/s)."""
-    from oracle import sdf_cpu
-
-    c = lambda t: t.detach().cpu().numpy()
-    st = dict(buffer_size=int(npm.buffer_pt_index.shape[0]), buffer_pt_index=c(npm.buffer_pt_index),
-              neural_points=c(npm.neural_points), point_orientations=c(npm.point_orientations),
-              geo_features=c(npm.geo_features), point_ts_create=c(npm.point_ts_create),
-              point_ts_update=c(npm.point_ts_create), point_certainties=c(npm.point_certainties),
-              free_gs_mask=c(npm.free_gs_mask), valid_gs_mask=c(npm.valid_gs_mask), travel_dist=c(npm.travel_dist),
-              cur_ts=0, diff_travel_dist_local=1e9, local_neural_points=c(npm.neural_points),
-              local_point_orientations=c(npm.point_orientations), local_geo_features=c(npm.geo_features),
-              local_point_certainties=c(npm.point_certainties), local_point_ts_update=c(npm.point_ts_create),
-              global2local=c(npm.global2local), neighbor_dx=c(npm.neighbor_dx), max_valid_dist2=npm.max_valid_dist2,
-              resolution=npm.resolution, after_pgo=False, temporal_local_map_on=False, nn_k=6,
-              weighted_first=weighted_first)
-    cm = sdf_cpu.NeuralPointMap(st)
-    mlp = sdf_cpu.MLP(dec.layers[0].weight.cpu(), dec.layers[0].bias.cpu(), dec.lout.weight.cpu(), dec.lout.bias.cpu(),
-                      dec.sdf_scale)
-    x = sdf_queries(npm, B, npm.neural_points.device).cpu()
-    with torch.no_grad():
-        sdf_cpu.mapper_sdf(cm, mlp, x)  # warm-up
-        threads = best_threads(lambda: sdf_cpu.mapper_sdf(cm, mlp, x[:min(B, 32768)]))
-        t0 = time.time()
-        for _ in range(reps):
-            s, _ = sdf_cpu.mapper_sdf(cm, mlp, x)
-        dt = (time.time() - t0) / reps
-    return {"value": round(B / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/sdf_cpu.py (reference torch op sequence) forward, 1 process, B={B} queries x {reps} reps on "
-                      f"the same {label} ({dt * reps:.1f} s of CPU work, {threads} torch threads = the fastest of 8..128; "
-                      f"host has {os.cpu_count()} logical cores)"}, s
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--mode", default="surfel", choices=["surfel", "3dgs"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sdf", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: put every rank on cuda:0 (use with --backend gloo)")
-    args = ap.parse_args()
-
-    # backward passes run on the calling thread: the hand-off to autograd's per-device worker thread and back costs
-    # 40-300 us per backward() depending on the box (measured: a two-operator graph 40 vs 73 us, the fused SDF step 178
-    # vs 463 us on two boxes of this pool), which is the whole budget of a 0.16 ms training step.  One line in the
-    # training script (INTEGRATION.md); no kernel, result or launch order changes.
-    if os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") != "1":      # A/B switch: 1 = torch's default worker thread
-        torch.autograd.set_multithreading_enabled(False)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    from pings_amd import _lib, dist as pdist, rasterizer as hr
-
-    L = _lib.lib()
-    L.pings_prof_enable.argtypes = [C.c_int]
-    L.pings_prof_report.argtypes = [C.c_char_p, C.c_size_t]
-    L.pings_prof_only.argtypes = [C.c_char_p]
-
-    P, W, H = args.gaussians, args.width, args.height
-    fx = fy = 1000.0 * W / 1920.0
-    cx, cy = W / 2 - 0.5, H / 2 - 0.5
-    means, col, op, scales, rot = synth_cloud(P, W, H, fx, fy, dev, seed=42)  # same cloud on every rank
-    settings = camera(W, H, fx, fy, cx, cy, 0.05, 110.0, rank, dev)
-    surfel = args.mode == "surfel"
-    if surfel:
-        rs = hr.SurfelRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=settings["tanfovx"], tanfovy=settings["tanfovy"],
-            bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=settings["viewmatrix"],
-            projmatrix=settings["projmatrix"], projmatrix_raw=settings["projmatrix_raw"],
-            patch_bbox=torch.tensor([0, 0, H - 1, W - 1], dtype=torch.float32, device=dev),
-            prcppoint=settings["prcppoint"], sh_degree=0, campos=settings["campos"], prefiltered=False, debug=False,
-            config=torch.tensor([1, 1, 1, 1, 1], dtype=torch.float32, device=dev))
-        rast = hr.SurfelGaussianRasterizer(rs)
-    else:
-        rs = hr.GS3DRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=settings["tanfovx"], tanfovy=settings["tanfovy"],
-            bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=settings["viewmatrix"],
-            projmatrix=settings["projmatrix"], projmatrix_raw=settings["projmatrix_raw"], sh_degree=0,
-            campos=settings["campos"], prefiltered=False, debug=False)
-        rast = hr.GS3DGaussianRasterizer(rs)
-
-    params = [t.requires_grad_(True) for t in (means, col, op, scales, rot)]
-    theta = torch.zeros(3, device=dev, requires_grad=True)
-    rho = torch.zeros(3, device=dev, requires_grad=True)
-    gg = torch.Generator(device=dev).manual_seed(7)
-    gC = torch.randn(3, H, W, generator=gg, device=dev)
-    gN = torch.randn(3, H, W, generator=gg, device=dev)
-    gD = torch.randn(1, H, W, generator=gg, device=dev)
-    gA = torch.randn(1, H, W, generator=gg, device=dev)
-    stats = {}
-    # N > 1: the exchange step of a multi-view iteration (SURVEY §8e, mapper.py:1581-1584): mean over ranks of the
-    # gradients of local_geo_features [N_np+1, 32] + local_color_features [N_np+1, 16] (ONE [N_np+1, 48] table, row-
-    # sparse: only the neural points this rank's view sees) and of the six decoder MLPs (flat bucket, async all-reduce
-    # overlapped with the table exchange).  The timed step stays the rasteriser step of the headline metric; the
-    # feature-gradient rows are the per-neural-point sums of the Gaussian gradients (8 Gaussians per point) — the
-    # spawn / decoder adjoint that produces the real values is measured in `render_step`, not here.
-    ex = None
-    if world > 1:
-        n_np = P // 8
-        g_tab = torch.zeros(n_np + 1, 48, device=dev)
-        mlp_shapes = [(128, 32), (128,), (24, 128), (24,), (128, 32), (128,), (32, 128), (32,), (128, 32), (128,),
-                      (24, 128), (24,), (128, 32), (128,), (8, 128), (8,), (128, 19), (128,), (24, 128), (24,),
-                      (64, 35), (64,), (1, 64), (1,)]
-        mlp_params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in mlp_shapes]
-        b_mlp = pdist.GradBucket(mlp_params, overlap=False)
-        ex = pdist.RowSparseExchange()
-
-    def exchange(radii):
-        b_mlp.zero()
-        g14 = torch.cat([params[0].grad, params[1].grad, params[2].grad, params[3].grad, params[4].grad], 1)
-        g_np = g14[:n_np * 8].view(n_np, 8, 14).sum(1)
-        b_mlp.flat.add_(g_np.mean())
-        b_mlp._launch()                                     # decoder bucket travels while the table is compacted
-        seen = (radii[:n_np * 8].view(n_np, 8) > 0).any(1)
-        rows = torch.nonzero(seen).flatten()                # the count sizes the gather (spawn reads it back anyway)
-        g_tab.zero_()
-        g_tab[rows] = torch.cat([g_np, g_np, g_np, g_np[:, :6]], 1)[rows]
-        ex.reduce_(g_tab, rows)
-        b_mlp.finish()
-
-    def step():
-        for p_ in params + [theta, rho]:
-            p_.grad = None
         m2d = torch.zeros_like(means)
         out = rast(means3D=params[0], means2D=m2d, colors_precomp=params[1], opacities=params[2],
                    scales=params[3], rotations=params[4], theta=theta, rho=rho)
@@ -1480,7 +1225,8 @@ def main():
                        "gaussians": P, "width": W, "height": H, "instances": int(I), "instances_blended": I_proc,
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
-            "autograd_multithreading": False,   # torch.autograd.set_multithreading_enabled(False), see main()
+            # False = torch.autograd.set_multithreading_enabled(False), see the top of main()
+            "autograd_multithreading": os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") == "1",
             "secondary_legs_timing": "best of 3 runs of `steps` calls (bench._timeit); the headline is one run of K steps",
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},
