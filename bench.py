@@ -1024,7 +1024,10 @@ def main():
         # as the Gaussians a neural point spawns are): what a view sees is then a coherent subset of the rows
         vox = torch.floor(means.detach()).to(torch.int64) + (1 << 20)
         own = torch.argsort((vox[:, 0] << 42) + (vox[:, 1] << 21) + vox[:, 2])[:n_np * 8].contiguous()
-        g_tab = torch.zeros(n_np + 1, 48, device=dev)
+        # the cameras of a rig look in different directions (IPB-Car: four, ipb_car.py:88-133): the local map holds every
+        # camera's sector and a view touches the rows of its own, so the shared table has world x P/8 rows and rank r's
+        # neural points are rows r P/8 ..
+        g_tab = torch.zeros(world * n_np + 1, 48, device=dev)
         mlp_shapes = [(128, 32), (128,), (24, 128), (24,), (128, 32), (128,), (32, 128), (32,), (128, 32), (128,),
                       (24, 128), (24,), (128, 32), (128,), (8, 128), (8,), (128, 19), (128,), (24, 128), (24,),
                       (64, 35), (64,), (1, 64), (1,)]
@@ -1039,9 +1042,10 @@ def main():
         b_mlp.flat.add_(g_np.mean())
         b_mlp._launch()                                     # decoder bucket travels while the table is compacted
         seen = (radii[own].view(n_np, 8) > 0).any(1)
-        rows = torch.nonzero(seen).flatten()                # the count sizes the gather (`render` reads it back anyway)
+        local = torch.nonzero(seen).flatten()               # the count sizes the gather (`render` reads it back anyway)
+        rows = local + rank * n_np
         g_tab.zero_()
-        g_tab[rows] = torch.cat([g_np, g_np, g_np, g_np[:, :6]], 1)[rows]
+        g_tab[rows] = torch.cat([g_np, g_np, g_np, g_np[:, :6]], 1)[local]
         ex.reduce_(g_tab, rows, n_rows=int(rows.numel()))   # geo + colour rows as ONE [N, 48] table
         b_mlp.finish()
 
@@ -1219,7 +1223,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.mode} rasteriser fwd+bwd, {P} Gaussians, {W}x{H}, one view per GPU"
                                    + (", then the multi-view exchange of SURVEY 8e over RCCL: row-sparse all-gather of the "
-                                      "visible neural points' feature-gradient rows [P/8+1, 48] + all-reduce of the six "
+                                      "visible neural points' feature-gradient rows (shared table [N x P/8 + 1, 48]: every "
+                                      "camera of the rig sees its own sector of the local map) + all-reduce of the six "
                                       "decoder MLPs" if world > 1 else ""),
                        "exchange": (ex.last if ex is not None else None),
                        "gaussians": P, "width": W, "height": H, "instances": int(I), "instances_blended": I_proc,
