@@ -357,7 +357,7 @@ def _c32(t):
 def _qf_forward(x, geo_tab, col_tab, npm, opts, want_n: bool):
     """Launches `pings_query_feature_forward`; returns (state, geo, colour, w [B,k], n [B,k,3] | None, cnt, cert)."""
     L = _L()
-    (query_ts, accumulate_stability, query_locally, query_geo, query_color, use_meas, use_valid) = opts
+    (query_ts, accumulate_stability, query_locally, query_geo, query_color, use_meas, use_valid) = opts[:7]
     dev = x.device
     q = _c32(x)
     B = q.shape[0]
@@ -365,6 +365,8 @@ def _qf_forward(x, geo_tab, col_tab, npm, opts, want_n: bool):
     nn_k = a.nn_k
     cfg = getattr(npm, "config", None)
     wf = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
+    if len(opts) > 7 and opts[7] is not None:       # layer_norm_on: rows are wanted per neighbour whatever the config says
+        wf = bool(opts[7])
     pts = (npm.local_neural_points if query_locally else npm.neural_points).detach().contiguous()
     quat = (npm.local_point_orientations if query_locally else npm.point_orientations)
     quat = quat.detach().contiguous() if quat is not None else None
@@ -677,15 +679,34 @@ def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = Non
         raise _lib.PingsHipError("query_feature runs on the HIP device only (got a CPU tensor); there is no CPU "
                                  "fallback — the CPU restatement is oracle/sdf_cpu.py (tests only)")
     cfg = self.config
-    if getattr(cfg, "layer_norm_on", False):
-        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (no shipped config sets it, "
-                                  "utils/config.py:95)")
+    layer_norm = bool(getattr(cfg, "layer_norm_on", False))
     feats = (self.local_geo_features if query_locally else self.geo_features) if query_geo_feature else None
     cfeats = (self.local_color_features if query_locally else self.color_features) if query_color_feature else None
     opts = (query_ts, bool(accumulate_stability), bool(query_locally), bool(query_geo_feature),
             bool(query_color_feature), bool(use_only_measured_points), bool(use_only_valid_points))
+    if layer_norm:
+        # config.layer_norm_on (utils/config.py:95; no shipped config sets it): `F.layer_norm` over the gathered feature
+        # rows BEFORE the neighbour vector is appended and before the weighted sum (:591-592, :605-606, :701-710).  The
+        # kernels deliver the per-neighbour rows; normalisation and, in weighted_first mode, the sum are the
+        # reference's own torch operators on the device (not a fused path: an option no configuration uses).
+        geo, col, w, cnt, cert = _query_feature_rows(self, query_points, feats, cfeats, opts + (False,))
+        F_ = torch.nn.functional
+
+        def norm(rows, dim):
+            if rows is None:
+                return None
+            rows = torch.cat((F_.layer_norm(rows[..., :dim], [dim]), rows[..., dim:]), dim=-1)
+            return torch.sum(rows * w, dim=1) if bool(cfg.weighted_first) else rows
+
+        return (norm(geo, feats.shape[1] if feats is not None else 0),
+                norm(col, cfeats.shape[1] if cfeats is not None else 0), w, cnt, cert)
     if bool(cfg.weighted_first):
         return _QueryFeature.apply(query_points, feats, cfeats, self, opts)
+    return _query_feature_rows(self, query_points, feats, cfeats, opts)
+
+
+def _query_feature_rows(self, query_points, feats, cfeats, opts):
+    """Per-neighbour mode of `query_feature`: ([B,k,Fg+3], [B,k,Fc+3], w [B,k,1], nn_counts, certainty)."""
     if not (torch.is_grad_enabled() and query_points.requires_grad):
         # no gradient to the query: run the kernel outside autograd, one node per table that wants a gradient
         with torch.no_grad():
@@ -706,6 +727,64 @@ def query_feature(self, query_points: torch.Tensor, query_ts: torch.Tensor = Non
     return geo, col, w, cnt, cert
 
 
+def fused_supported(npm, decoder) -> bool:
+    """Whether the fused SDF kernels cover this (map, decoder) pair: one hidden level of at most 64 units, ReLU, biases,
+    F <= 61, no layer norm — every shipped configuration (pings.py:147, utils/config.py:95,145-146).  Everything else
+    runs `_sdf_composed`: the same result from `query_feature` + the decoder's own layers, on the device."""
+    cfg = getattr(npm, "config", None)
+    if cfg is not None and getattr(cfg, "layer_norm_on", False):
+        return False
+    layers = getattr(decoder, "layers", None)
+    if layers is None or len(layers) != 1 or getattr(decoder, "use_leaky_relu", False):
+        return False
+    l0, lo = layers[0], decoder.lout
+    if l0.bias is None or lo.bias is None or lo.weight.shape[0] != 1:
+        return False
+    return int(l0.weight.shape[0]) <= 64 and int(l0.weight.shape[1]) - 3 <= 61
+
+
+def _sdf_composed(npm, decoder, x, need_grad=False, need_certainty=False, query_locally=True,
+                  use_only_measured_points=True, use_only_valid_points=False, need_std=False, train=False):
+    """`Mapper.sdf` composed from its parts (utils/mapper.py:2273-2289: `query_feature` -> `Decoder.sdf` -> IDW sum) for
+    the decoder / map options the fused kernels do not implement (`layer_norm_on`, leaky ReLU, more than one hidden
+    level, wide layers): the search, gather and weights are the HIP `query_feature`, the decoder is the module's own
+    `sdf` (fused when its shape allows, else its torch layers on the device).  Same return tuple as `sdf_fused`;
+    `train=True` keeps the graph (returns sdf with grad_fn) instead of detaching."""
+    cfg = getattr(npm, "config", None)
+    weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
+    xq = x if train else x.detach()
+    want_gx = need_grad and not train
+    if want_gx:
+        xq = xq.clone().requires_grad_(True)
+    with torch.enable_grad() if (want_gx or train) else torch.no_grad():
+        geo, _, w, cnt, cert = query_feature(npm, xq, accumulate_stability=False, query_locally=query_locally,
+                                             use_only_measured_points=use_only_measured_points,
+                                             use_only_valid_points=use_only_valid_points)
+        dec_sdf = getattr(decoder, "sdf", None)
+        if dec_sdf is None:
+            from . import decoder as _dec
+
+            pred = _dec.sdf(decoder, geo)
+        else:
+            pred = dec_sdf(geo)
+        std = None
+        if weighted_first:
+            s_ = pred
+        else:
+            mean = torch.sum(pred * w, dim=1)
+            if need_std:
+                std = torch.sqrt(torch.sum(w * (pred - mean.unsqueeze(-1)) ** 2, dim=1)).squeeze(1)
+            s_ = mean.squeeze(1)
+        grad = torch.autograd.grad(s_.sum(), xq)[0] if want_gx else None
+    if not train:
+        s_ = s_.detach()
+        std = std.detach() if std is not None else None
+    res = (s_, grad, cnt, cert if need_certainty else None)
+    if need_std:
+        res = res + (std if std is not None else torch.zeros_like(s_),)
+    return res
+
+
 def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certainty: bool = False,
               query_locally: bool = True, use_only_measured_points: bool = True,
               use_only_valid_points: bool = False, need_std: bool = False):
@@ -716,23 +795,20 @@ def sdf_fused(npm, decoder, x: torch.Tensor, need_grad: bool = False, need_certa
     sdf_std[B] (spread of the per-neighbour predictions, utils/tracker.py:303-313).  `decoder` is the
     reference's `Decoder` (model/decoder.py) with one hidden level, or any object with
     `layers[0].weight/.bias`, `lout.weight/.bias`, `sdf_scale`."""
+    if not fused_supported(npm, decoder):
+        return _sdf_composed(npm, decoder, x, need_grad, need_certainty, query_locally, use_only_measured_points,
+                             use_only_valid_points, need_std)
     L = _L()
     q = x.detach().to(torch.float32).contiguous()
     B = q.shape[0]
     cfg = getattr(npm, "config", None)
-    if cfg is not None and getattr(cfg, "layer_norm_on", False):
-        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
     weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
     a = _map_args(npm, bool(npm.temporal_local_map_on and query_locally), use_only_measured_points,
                  use_only_valid_points, query_locally)
-    if len(decoder.layers) != 1:
-        raise NotImplementedError("sdf_fused supports decoders with one hidden level (every shipped config)")
     W1 = decoder.layers[0].weight.detach().to(torch.float32).contiguous()
     b1 = decoder.layers[0].bias.detach().to(torch.float32).contiguous()
     W2 = decoder.lout.weight.detach().to(torch.float32).contiguous()
     b2 = decoder.lout.bias.detach().to(torch.float32).contiguous()
-    if getattr(decoder, "use_leaky_relu", False):
-        raise NotImplementedError("sdf_fused implements ReLU decoders (config.mlp_leaky_relu = False)")
     feats = (npm.local_geo_features if query_locally else npm.geo_features).detach().contiguous()
     pts = (npm.local_neural_points if query_locally else npm.neural_points).contiguous()
     quat = (npm.local_point_orientations if query_locally else npm.point_orientations).contiguous()
@@ -916,11 +992,11 @@ def sdf_train(npm, decoder, x: torch.Tensor, query_locally: bool = True, use_onl
     (first order: use `query_feature` when the loss needs a gradient of the gradient, mapper.py:1448).
     Returns (sdf[B], nn_counts[B])."""
     cfg = getattr(npm, "config", None)
-    if cfg is not None and getattr(cfg, "layer_norm_on", False):
-        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
+    if not fused_supported(npm, decoder):
+        s_, _, cnt, _ = _sdf_composed(npm, decoder, x, False, False, query_locally, use_only_measured_points,
+                                      use_only_valid_points, train=True)
+        return s_, cnt
     weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
-    if len(decoder.layers) != 1 or getattr(decoder, "use_leaky_relu", False):
-        raise NotImplementedError("sdf_train supports one-hidden-level ReLU decoders (every shipped config)")
     feats = npm.local_geo_features if query_locally else npm.geo_features
     l0, lo = decoder.layers[0], decoder.lout
     return _SdfTrain.apply(x, feats, l0.weight, l0.bias, lo.weight, lo.bias, npm, float(decoder.sdf_scale),
@@ -999,11 +1075,9 @@ def numerical_gradient(npm, decoder, x, sdf_x=None, eps=0.02, two_side=True):
     only — the defaults `Mapper.sdf` uses), differentiable w.r.t. `local_geo_features`, the decoder and (one-sided)
     `sdf_x`; `x` itself is treated as a constant (callers with `x.requires_grad` take the composed path)."""
     cfg = getattr(npm, "config", None)
-    if cfg is not None and getattr(cfg, "layer_norm_on", False):
-        raise NotImplementedError("config.layer_norm_on is not implemented on the HIP path (utils/config.py:95)")
+    if not fused_supported(npm, decoder):
+        raise NotImplementedError("numerical_gradient: the fused node needs the fused SDF kernels (caller composes)")
     weighted_first = bool(cfg.weighted_first) if cfg is not None else bool(npm.weighted_first)
-    if len(decoder.layers) != 1 or getattr(decoder, "use_leaky_relu", False):
-        raise NotImplementedError("numerical_gradient supports one-hidden-level ReLU decoders (every shipped config)")
     l0, lo = decoder.layers[0], decoder.lout
     return _NumGrad.apply(x, sdf_x, npm.local_geo_features, l0.weight, l0.bias, lo.weight, lo.bias, npm,
                           float(decoder.sdf_scale), weighted_first, float(eps), bool(two_side))
