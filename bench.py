@@ -23,7 +23,16 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+# The ROCm runtime completes a blocked host wait (hipStreamSynchronize, torch's .item() / nonzero / synchronize) through
+# an interrupt; with HSA_ENABLE_INTERRUPT=0 it polls the completion signal in user space instead.  On a healthy box the
+# two measure the same (A/B in profiles/README.md, r03: every leg within noise); on one box of this pool blocked waits
+# returned only with a 60 Hz tick (16 ms each: headline 11.7 instead of 1.15 ms/step).  The library's own read-backs
+# poll pinned memory and do not depend on this; the variable covers torch's waits (the mapper's boolean-mask indexing
+# in `sdf_step`, the synchronise that ends every timed region).  Set before the runtime initialises; an explicit
+# setting in the environment wins.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
@@ -1232,6 +1241,7 @@ def main():
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},
             # False = torch.autograd.set_multithreading_enabled(False), see the top of main()
             "autograd_multithreading": os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") == "1",
+            "hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"),   # see the top of this file
             "secondary_legs_timing": "best of 3 runs of `steps` calls (bench._timeit); the headline is one run of K steps",
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},

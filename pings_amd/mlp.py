@@ -163,7 +163,8 @@ class _FusedMLPGroup(torch.autograd.Function):
         parts = flat.split(sizes)
         base = flat.data_ptr()
         in_cols = [xs[g].shape[1] if ctx.need_x[g] else 0 for g in range(J)]
-        gx_flat = torch.empty(N * sum(in_cols), **f32) if any(in_cols) else None
+        alloc = torch.zeros if (ctx.fc is not None and torch.is_anomaly_enabled()) else torch.empty   # see render_core
+        gx_flat = alloc(N * sum(in_cols), **f32) if any(in_cols) else None
         gx_off = 0
         p_off = 0
         for g in range(J):

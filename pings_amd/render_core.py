@@ -191,6 +191,7 @@ class _SpawnRaster(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_color, g_normal, g_depth, g_alpha, _g_radii, _g_perg, g_xyz, g_scale, g_rot, g_galpha,
                  g_gcolor, g_alpha_all, _g_free):
         L = _lib.lib()
@@ -241,7 +242,10 @@ class _SpawnRaster(torch.autograd.Function):
         prm = dict(ctx.prm)
         prm["n"] = n_sel
         p = _spawn.SpawnParams(**prm)
-        outs = [torch.empty_like(r) for r in raws]
+        # rows behind the selected ones are never written (nor read downstream); under anomaly detection autograd scans
+        # every returned gradient for NaN, so only then are they cleared
+        alloc = torch.zeros_like if torch.is_anomaly_enabled() else torch.empty_like
+        outs = [alloc(r) for r in raws]
         gaa = gc(g_alpha_all)
         _lib.check(L.pings_spawn_backward(
             C.byref(p), *[_lib.ptr(t) for t in raws], _lib.ptr(quat), _lib.ptr(base), _lib.ptr(dist_ratio),
