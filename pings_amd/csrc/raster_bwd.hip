@@ -385,9 +385,157 @@ __device__ inline float wave_incl_scan_add(float x) {
 // value of lane - 1 (lane 0 gets `first`)
 __device__ inline float wave_shr1(float x, float first) { return dpp_f<0x138, 0xf>(first, x); }
 
+// The same scans inside lane GROUPS of G = 16 / 32 / 64 lanes (a 16-lane DPP row, a half wave, the wave): a chunk with
+// at most G records puts 64 / G pixels on the wave at once, each on its own group (grp_* below).
+template <int G>
+__device__ inline float grp_incl_scan_mul(float x) {
+  x *= dpp_f<0x111, 0xf>(1.f, x);
+  x *= dpp_f<0x112, 0xf>(1.f, x);
+  x *= dpp_f<0x114, 0xf>(1.f, x);
+  x *= dpp_f<0x118, 0xf>(1.f, x);
+  if (G >= 32) x *= dpp_f<0x142, 0xa>(1.f, x);
+  if (G >= 64) x *= dpp_f<0x143, 0xc>(1.f, x);
+  return x;
+}
+template <int G>
+__device__ inline float grp_incl_scan_add(float x) {
+  x += dpp_f<0x111, 0xf>(0.f, x);
+  x += dpp_f<0x112, 0xf>(0.f, x);
+  x += dpp_f<0x114, 0xf>(0.f, x);
+  x += dpp_f<0x118, 0xf>(0.f, x);
+  if (G >= 32) x += dpp_f<0x142, 0xa>(0.f, x);
+  if (G >= 64) x += dpp_f<0x143, 0xc>(0.f, x);
+  return x;
+}
+// value of the previous lane of the group (the group's first lane gets `first`)
+template <int G>
+__device__ inline float grp_shr1(float x, float first, int lane) {
+  if (G == 16) return dpp_f<0x111, 0xf>(first, x);          // row_shr:1, lanes without a source keep `first`
+  const float y = dpp_f<0x138, 0xf>(first, x);               // wave_shr:1
+  return (G == 32 && lane == 32) ? first : y;
+}
+
 struct PopOp {
   __host__ __device__ uint32_t operator()(const uint8_t& m) const { return (uint32_t)__builtin_popcount((unsigned)m & 15u); }
 };
+
+#ifdef PINGS_BWD_STATS
+#define STATS_PARAMS , unsigned long long& st_dead, unsigned long long& st_any, unsigned long long& st_exec, unsigned long long& st_valid
+#define STATS_ARGS , st_dead, st_any, st_exec, st_valid
+#else
+#define STATS_PARAMS
+#define STATS_ARGS
+#endif
+
+// The pixel loop of blend_bwd_scan_kernel for one chunk of `take` <= G records: 64 / G pixels per step, lane l = record
+// l % G of pixel pp0 + l / G (records are replicated over the groups by the caller).  Per pixel the arithmetic is the
+// one-pixel form's, op for op; a lane's 16 sums run over its group's pixels and the groups are added at the end
+// (fixed order: deterministic).
+template <int MODE, int G>
+__device__ inline void scan_pixels(float4 (*sPix)[4], int lane, int take, int e, int min_e, const float4& a,
+                                   const float4& b, const float4& c, const float4& nn, float (&v)[16] STATS_PARAMS) {
+  constexpr int NG = 64 / G;
+  const int grp = lane / G;
+  const float zlo = a.w - b.w, zhi = a.w + b.w;
+  for (int pp0 = 0; pp0 < 64; pp0 += NG) {
+    const int pp = pp0 + grp;
+    const float4 s0 = sPix[pp][0];
+    const int last_p = (int)__float_as_uint(s0.z);
+    if (!__any(last_p > min_e)) {                      // these pixels had stopped before the chunk's first record
+#ifdef PINGS_BWD_STATS
+      st_dead += NG;
+#endif
+      continue;
+    }
+    const float4 s1 = sPix[pp][1], s2 = sPix[pp][2], s3 = sPix[pp][3];
+    const float T_p = s0.x, R_p = s0.y, coefT = s0.w;
+    const float dx = a.x - s2.w;
+    const float dy = a.y - s3.x;
+    const float p0 = -0.5f * (b.x * dx * dx);
+    const float pxy = b.y * dx;
+    const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;   // the forward pass' op order
+    const float Gs = __expf(power);
+    const float raw = a.z * Gs;
+    const float alpha = fminf(ALPHA_MAX, raw);
+    const bool valid = (e < last_p) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
+#ifdef PINGS_BWD_STATS
+    if (!__any(valid)) st_any += NG; else { st_exec += NG; st_valid += (unsigned)__popcll(__ballot(valid)); }
+#endif
+    if (!__any(valid)) continue;                          // no record reaches any of these pixels: their state
+                                                          // (T / 1, R + 0) and every gradient sum stay as they are
+    const float av = valid ? alpha : 0.f;
+    const float P_in = grp_incl_scan_mul<G>(1.0f - av);   // product of (1 - alpha) over this and the records behind
+    const float P_ex = grp_shr1<G>(P_in, 1.0f, lane);
+    const float inv_P = __builtin_amdgcn_rcpf(P_in);
+    const float Tn = T_p * inv_P;                        // transmittance in front of this record
+    const float inv_one_m = P_ex * inv_P;                // 1 / (1 - alpha)
+    const float w = av * Tn;
+    float S_in;
+    {
+    // gradient accumulation only (alpha / validity were decided above in the forward pass' op order): multiply-adds
+    // may fuse here
+#pragma clang fp contract(fast)
+    // s = (upstream gradient) . (features of this record at this pixel)
+    float sdot = (c.x * s1.x + c.y * s1.y) + c.z * s1.z;
+    v[G_R] = fmaf(s1.x, w, v[G_R]);
+    v[G_G] = fmaf(s1.y, w, v[G_G]);
+    v[G_B] = fmaf(s1.z, w, v[G_B]);
+    if (MODE == MODE_SURFEL) {
+      sdot += (nn.x * s2.x + nn.y * s2.y) + nn.z * s2.z;
+      const float den = (nn.x * s3.y + nn.y * s3.z) + nn.z;
+      const bool hit = den < -DEN_EPS;
+      const float inv_den = __builtin_amdgcn_rcpf(den);
+      const float d0 = hit ? c.w * inv_den : a.w;
+      const float d = fminf(fmaxf(d0, zlo), zhi);
+      sdot = fmaf(d, s1.w, sdot);
+      const float gd = s1.w * w;
+      const bool lo = d0 < zlo, hi = d0 > zhi;
+      const bool mid = !lo && !hi;
+      v[G_ZLO] += lo ? gd : 0.f;
+      v[G_ZHI] += hi ? gd : 0.f;
+      const float gq = (mid && hit) ? gd * inv_den : 0.f;
+      v[G_Q] += gq;
+      v[G_PZ] += (mid && !hit) ? gd : 0.f;
+      const float gden = -gq * d0;
+      v[G_NX] += fmaf(gden, s3.y, s2.x * w);
+      v[G_NY] += fmaf(gden, s3.z, s2.y * w);
+      v[G_NZ] += s2.z * w + gden;
+    } else {
+      sdot = fmaf(a.w, s1.w, sdot);
+      v[G_PZ] = fmaf(s1.w, w, v[G_PZ]);
+    }
+    const float ws = w * sdot;
+    S_in = grp_incl_scan_add<G>(ws);                     // w s over this and the records behind (in the chunk)
+    const float R_l = R_p + grp_shr1<G>(S_in, 0.f, lane); // blended behind this record, dotted with the gradient
+    // dL/dalpha = T s - (R - coefT) / (1 - alpha)
+    float dLda = fmaf(Tn, sdot, (coefT - R_l) * inv_one_m);
+    dLda = (valid && raw <= ALPHA_MAX) ? dLda : 0.f;     // no gradient through the active 0.99 clamp
+    v[G_OPAC] = fmaf(Gs, dLda, v[G_OPAC]);
+    const float dLp = raw * dLda;
+    const float qx = b.x * dx + b.y * dy, qy = b.y * dx + b.z * dy;
+    v[G_MX] -= dLp * qx;
+    v[G_MY] -= dLp * qy;
+    v[G_CONX] += 0.5f * qx * qx * dLp;
+    v[G_CONY] += qx * qy * dLp;
+    v[G_CONZ] += 0.5f * qy * qy * dLp;
+    }
+    if ((lane & (G - 1)) == G - 1) {                     // the group's last lane: pixel state after the whole chunk
+      sPix[pp][0].x = Tn;
+      sPix[pp][0].y = R_p + S_in;
+    }
+  }
+  if (G < 64) {                                          // the groups hold partial sums of the SAME records: add them
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (G == 16) v[k] += __shfl_xor(v[k], 16, 64);
+      v[k] += __shfl_xor(v[k], 32, 64);
+    }
+  }
+}
+
+#ifdef PINGS_BWD_STATS  // diagnostic build only: loop-efficiency counters of blend_bwd_scan_kernel
+__device__ unsigned long long g_bwd_stats[8];
+#endif
 
 template <int MODE>
 __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
@@ -460,6 +608,9 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
   const uint2 range = ranges[tile];
   const uint32_t below = (1u << q) - 1u;
   int nq = 0;
+#ifdef PINGS_BWD_STATS
+  unsigned long long st_chunks = 0, st_dead = 0, st_any = 0, st_exec = 0, st_valid = 0, st_take = 0;
+#endif
 
   while (true) {
     // ---- queue the next relevant entries (entries behind `pos` are done)
@@ -482,9 +633,11 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
     }
     if (nq == 0) break;
     const int take = nq < 64 ? nq : 64;
-    const bool act = lane < take;
-    const int e = act ? sQe[lane] : 0x7FFFFFFF;      // an idle lane is never `valid`
-    const uint32_t slot = act ? sQs[lane] : 0u;
+    // records replicated over the lane groups of scan_pixels: group size 16 / 32 / 64 by the chunk's record count
+    const int gl = take <= 16 ? (lane & 15) : (take <= 32 ? (lane & 31) : lane);
+    const bool act = gl < take;
+    const int e = act ? sQe[gl] : 0x7FFFFFFF;        // an idle lane is never `valid`
+    const uint32_t slot = act ? sQs[gl] : 0u;
     const int rest = nq - take;                        // < 64: shift the remainder to the queue's front
     const int me = lane < rest ? sQe[take + lane] : 0;
     const uint32_t ms = lane < rest ? sQs[take + lane] : 0u;
@@ -502,90 +655,20 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
       if (MODE == MODE_SURFEL) nn = rec[4 * (size_t)g + 3];
       row = cidx[slot] + (uint32_t)__builtin_popcount((unsigned)qmask[slot] & below);
     }
-    const float zlo = a.w - b.w, zhi = a.w + b.w;
     float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = 0.f;
 
-    for (int pp = 0; pp < 64; ++pp) {
-      const float4 s0 = sPix[pp][0];
-      const int last_p = (int)__float_as_uint(s0.z);
-      if (last_p <= min_e) continue;                   // this pixel had stopped before the chunk's first record
-      const float4 s1 = sPix[pp][1], s2 = sPix[pp][2], s3 = sPix[pp][3];
-      const float T_p = s0.x, R_p = s0.y, coefT = s0.w;
-      const float dx = a.x - s2.w;
-      const float dy = a.y - s3.x;
-      const float p0 = -0.5f * (b.x * dx * dx);
-      const float pxy = b.y * dx;
-      const float power = (p0 - 0.5f * (b.z * dy * dy)) - pxy * dy;   // the forward pass' op order
-      const float G = __expf(power);
-      const float raw = a.z * G;
-      const float alpha = fminf(ALPHA_MAX, raw);
-      const bool valid = (e < last_p) && (power <= 0.0f) && (alpha >= ALPHA_MIN);
-      if (!__any(valid)) continue;                          // no record of the chunk reaches this pixel: its state
-                                                            // (T / 1, R + 0) and every gradient sum stay as they are
-      const float av = valid ? alpha : 0.f;
-      const float P_in = wave_incl_scan_mul(1.0f - av);     // product of (1 - alpha) over this and the records behind
-      const float P_ex = wave_shr1(P_in, 1.0f);
-      const float inv_P = __builtin_amdgcn_rcpf(P_in);
-      const float Tn = T_p * inv_P;                        // transmittance in front of this record
-      const float inv_one_m = P_ex * inv_P;                // 1 / (1 - alpha)
-      const float w = av * Tn;
-      float S_in;
-      {
-      // gradient accumulation only (alpha / validity were decided above in the forward pass' op order): multiply-adds
-      // may fuse here
-#pragma clang fp contract(fast)
-      // s = (upstream gradient) . (features of this record at this pixel)
-      float sdot = (c.x * s1.x + c.y * s1.y) + c.z * s1.z;
-      v[G_R] = fmaf(s1.x, w, v[G_R]);
-      v[G_G] = fmaf(s1.y, w, v[G_G]);
-      v[G_B] = fmaf(s1.z, w, v[G_B]);
-      if (MODE == MODE_SURFEL) {
-        sdot += (nn.x * s2.x + nn.y * s2.y) + nn.z * s2.z;
-        const float den = (nn.x * s3.y + nn.y * s3.z) + nn.z;
-        const bool hit = den < -DEN_EPS;
-        const float inv_den = __builtin_amdgcn_rcpf(den);
-        const float d0 = hit ? c.w * inv_den : a.w;
-        const float d = fminf(fmaxf(d0, zlo), zhi);
-        sdot = fmaf(d, s1.w, sdot);
-        const float gd = s1.w * w;
-        const bool lo = d0 < zlo, hi = d0 > zhi;
-        const bool mid = !lo && !hi;
-        v[G_ZLO] += lo ? gd : 0.f;
-        v[G_ZHI] += hi ? gd : 0.f;
-        const float gq = (mid && hit) ? gd * inv_den : 0.f;
-        v[G_Q] += gq;
-        v[G_PZ] += (mid && !hit) ? gd : 0.f;
-        const float gden = -gq * d0;
-        v[G_NX] += fmaf(gden, s3.y, s2.x * w);
-        v[G_NY] += fmaf(gden, s3.z, s2.y * w);
-        v[G_NZ] += s2.z * w + gden;
-      } else {
-        sdot = fmaf(a.w, s1.w, sdot);
-        v[G_PZ] = fmaf(s1.w, w, v[G_PZ]);
-      }
-      const float ws = w * sdot;
-      S_in = wave_incl_scan_add(ws);                       // w s over this and the records behind (in the chunk)
-      const float R_l = R_p + wave_shr1(S_in, 0.f);        // blended behind this record, dotted with the gradient
-      // dL/dalpha = T s - (R - coefT) / (1 - alpha)
-      float dLda = fmaf(Tn, sdot, (coefT - R_l) * inv_one_m);
-      dLda = (valid && raw <= ALPHA_MAX) ? dLda : 0.f;     // no gradient through the active 0.99 clamp
-      v[G_OPAC] = fmaf(G, dLda, v[G_OPAC]);
-      const float dLp = raw * dLda;
-      const float qx = b.x * dx + b.y * dy, qy = b.y * dx + b.z * dy;
-      v[G_MX] -= dLp * qx;
-      v[G_MY] -= dLp * qy;
-      v[G_CONX] += 0.5f * qx * qx * dLp;
-      v[G_CONY] += qx * qy * dLp;
-      v[G_CONZ] += 0.5f * qy * qy * dLp;
-      }
-      if (lane == 63) {                                    // pixel state after the whole chunk
-        sPix[pp][0].x = Tn;
-        sPix[pp][0].y = R_p + S_in;
-      }
-    }
-    if (act) {
+#ifdef PINGS_BWD_STATS
+    ++st_chunks; st_take += (unsigned)take;
+#endif
+    // Chunks that hold at most 16 / 32 records (short lists: a quadrant of a mapping view sees ~20 relevant records)
+    // put four / two pixels on the wave at once: lane l works on record l % G for pixel pp0 + l / G.  Measured before
+    // this split on the bench's mapping view: 21 records per chunk, 6.9 valid lanes of 64 per pixel iteration.
+    if (take <= 16) scan_pixels<MODE, 16>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
+    else if (take <= 32) scan_pixels<MODE, 32>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
+    else scan_pixels<MODE, 64>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
+    if (act && gl == lane) {                           // every group holds the same sums: the first one stores
       float4* dst = reinterpret_cast<float4*>(rows) + (size_t)row * 4;
       dst[0] = make_float4(v[0], v[1], v[2], v[3]);
       dst[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -593,6 +676,12 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
       dst[3] = make_float4(v[12], v[13], v[14], v[15]);
     }
   }
+#ifdef PINGS_BWD_STATS
+  if (lane == 0) {
+    atomicAdd(&g_bwd_stats[0], st_chunks); atomicAdd(&g_bwd_stats[1], st_dead); atomicAdd(&g_bwd_stats[2], st_any);
+    atomicAdd(&g_bwd_stats[3], st_exec); atomicAdd(&g_bwd_stats[4], st_valid); atomicAdd(&g_bwd_stats[5], st_take);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- balanced per-Gaussian row sums
@@ -1080,3 +1169,15 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   }
   return PINGS_OK;
 }
+
+#ifdef PINGS_BWD_STATS
+PINGS_API int pings_debug_bwd_stats(unsigned long long* out8, int reset) {
+  PINGS_HIP_CHECK(hipDeviceSynchronize());
+  PINGS_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pings::raster::g_bwd_stats), 64));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    PINGS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pings::raster::g_bwd_stats), z, 64));
+  }
+  return PINGS_OK;
+}
+#endif
