@@ -37,6 +37,7 @@ namespace raster {
 struct KParams {
   int P, W, H, gx, gy;
   int front_only;
+  float occ_amin;    // smallest per-tile alpha bound that is worth an occlusion-budget entry (see preprocess_kernel)
   int rect_3sigma;   // PINGS_RASTER_RECT=3sigma: the published 3DGS tile square (A/B: measures what the ellipse box drops)
   float fx, fy, limx, limy, scale_mod;
   const float* view;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       // half the pairs of a 7 x 7 rectangle.  The bounds are widened by 0.02 tile against rounding; a Gaussian whose
       // minor semi-axis sqrt(thr lambda_min) is below 7.5 px (threshold 50 = 7.07^2: slack again) cannot hold the
       // 15 x 15 pixel square of a tile at all.
-      const float thr_u = 2.0f * logf(255.0f * opac);
+      const float thr_u = 2.0f * logf(opac / p.occ_amin);
       const float lam_min = mid - sqrtf(fmaxf(mid * mid - det, 0.0f));
       uint32_t inner = 0xFFFFFFFFu;   // empty
       if (thr_u * lam_min >= 50.0f) {
@@ -320,13 +321,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   }
 }
 
-// Depth ranks are dealt to waves round-robin (lane l of wave w owns rank l*num_waves + w): the
-// nearest Gaussians, which cover the most tiles, sit at neighbouring ranks and would otherwise
-// all land in the first waves.
+// Depth ranks -> lanes.  The nearest Gaussians cover the most tiles and sit at neighbouring ranks: dealt out in rank
+// order they would all land in the first waves.  The first quarter of the ranks is therefore dealt round-robin,
+// one rank per wave at a time (lane l < 16 of wave w: rank l num_waves + w); behind it the footprints are small and
+// even, and ranks go out in runs of 16 (quarter q >= 1 of wave w: ranks 16 (q num_waves + w) .. + 15), so that the
+// per-rank loads and stores are 64-byte segments instead of one memory transaction per lane.  (Runs of 16 from rank
+// 0 on: Metric-1's duplicate pass 0.054 -> 0.168 ms — sixteen screen-filling footprints in one wave; C3 0.078 ->
+// 0.037 ms either way.)
 __device__ inline int strided_rank(int P) {
   const int num_waves = (int)(gridDim.x * (blockDim.x >> 6));
   const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const int r = (int)(threadIdx.x & 63) * num_waves + wave;
+  const int lane = (int)(threadIdx.x & 63);
+  const int r = lane < 16 ? lane * num_waves + wave : ((lane >> 4) * num_waves + wave) * 16 + (lane & 15);
   return r < P ? r : -1;
 }
 
@@ -379,9 +385,11 @@ __device__ inline void walk_rects(const RectLane& me, int gx, Serial serial, Coo
   }
 }
 
-__device__ inline RectLane rect_lane(int r, const uint32_t* __restrict__ gidx_sorted, const uint4* __restrict__ rect) {
+// ranks from nvalid on are the culled Gaussians (no tiles): their index and rectangle are not even loaded
+__device__ inline RectLane rect_lane(int r, const uint32_t* __restrict__ gidx_sorted, const uint4* __restrict__ rect,
+                                     uint32_t nvalid) {
   RectLane me{0u, 0u, 0, 0, 1};
-  if (r >= 0) {
+  if (r >= 0 && (uint32_t)r < nvalid) {
     me.g = gidx_sorted[r];
     const uint4 rc = rect[me.g];
     me.n = rc.w;
@@ -618,7 +626,8 @@ __global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
                                                           const uint32_t* __restrict__ nvalid, int num_tiles,
                                                           uint32_t* __restrict__ bucket) {
   const int r = strided_rank(P);
-  RectLane me = rect_lane(r, gidx_sorted, rect);
+  const uint32_t nv = *nvalid;
+  RectLane me = rect_lane(r, gidx_sorted, rect, nv);
   if (me.n != 0u) {   // walk only the inner rectangle (preprocess_kernel): tiles outside it cannot be covered
     const uint4 rc = rect[me.g];
     const int x0 = me.xmin + (int)(rc.x & 255u), x1 = (int)(rc.z & 0xFFFF) - (int)((rc.x >> 8) & 255u);
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(256) void occl_budget_kernel(int P, int gx, int nb,
     ra = rec[4 * (size_t)me.g + 0];
     rb = rec[4 * (size_t)me.g + 1];
   }
-  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  const uint32_t bk = rank_bucket(r, nb, nv);
   // bucket-major layout: the 64 tiles a wave handles in one step are neighbours in a tile row, so its atomics
   // hit contiguous words (scattered 4-byte atomics run an order of magnitude slower)
   auto add = [&](int tx, int ty, float mx, float my, float o, float cx, float cy, float cz, uint32_t b) {
@@ -701,8 +710,9 @@ __global__ __launch_bounds__(256) void count_kept_kernel(int P, int gx, int nb,
                                                          unsigned long long* __restrict__ pairs_full) {
   const int r = strided_rank(P);
   const int lane = threadIdx.x & 63;
-  const RectLane me = rect_lane(r, gidx_sorted, rect);
-  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  const uint32_t nv = *nvalid;
+  const RectLane me = rect_lane(r, gidx_sorted, rect, nv);
+  const uint32_t bk = rank_bucket(r, nb, nv);
   uint32_t kept = 0, sb = 0, acc = 0;
   int cur = -1;
   walk_rects(
@@ -749,8 +759,9 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int nb,
                                                          uint32_t* __restrict__ gval,
                                                          uint32_t* __restrict__ slot_val) {
   const int r = strided_rank(P);
-  const RectLane me = rect_lane(r, gidx_sorted, rect);
-  const uint32_t bk = rank_bucket(r, nb, *nvalid);
+  const uint32_t nv = *nvalid;
+  const RectLane me = rect_lane(r, gidx_sorted, rect, nv);
+  const uint32_t bk = rank_bucket(r, nb, nv);
   uint32_t o = r >= 0 ? offsets_sorted[r] - tiles_sorted[r] : 0u;  // first slot of this Gaussian
   uint32_t sb = 0, so = 0, sg = 0;
   walk_rects(
@@ -1900,6 +1911,13 @@ static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   kp.gy = ceil_div(kp.H, TILE);
   kp.front_only = s->front_only;
   kp.rect_3sigma = 0;
+  // Tiles a Gaussian covers with less than this alpha everywhere are left out of the occlusion budget: fewer entries
+  // is still a lower bound of the opacity in front (conservative: the kept lists can only grow, results unchanged),
+  // and the faint rim of every footprint was most of the budget pass's atomics.  Metric-1 sweep (r03): 1/255 -> 0.15
+  // takes occl_budget 0.116 -> 0.053 ms and the step 1.136 -> 1.072 ms for 7.8 % more instances (0.2: 17 % more for
+  // 0.005 ms); C2 / C3 unchanged.  PINGS_OCC_AMIN overrides (1/255 = every covered tile, the round-2 behaviour).
+  kp.occ_amin = 0.15f;
+  if (const char* e = getenv("PINGS_OCC_AMIN")) kp.occ_amin = fminf(fmaxf((float)atof(e), 1.0f / 255.0f), 0.99f);
   if (const char* e = getenv("PINGS_RASTER_RECT")) kp.rect_3sigma = e[0] == '3';
   kp.fx = (float)((double)kp.W / (2.0 * s->tanfovx));
   kp.fy = (float)((double)kp.H / (2.0 * s->tanfovy));
@@ -2068,8 +2086,8 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
         PINGS_LAUNCH_CHECK();
       }
     } else {
+      // every tile keeps every rank bucket (OCC_ALL); nvalid stays: rect_lane skips the culled ranks with it
       PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bsat, 0xFF, sizeof(uint16_t) * (size_t)num_tiles, st));
-      PINGS_HIP_CHECK(hipMemsetAsync(gs.nvalid, 0, sizeof(uint32_t), st));
     }
     {
       pings::prof::Scope ps("tile_count_scan", st);
