@@ -41,6 +41,20 @@ struct BParams {
 };
 
 constexpr int BATCH = 64;
+// blend_bwd_scan_kernel: tiles whose largest per-pixel contributor count reaches the threshold get four waves per
+// quadrant (PINGS_BWD_LONG overrides the threshold, 0 = never); at most LONG_TILES_MAX tiles per frame.  C3 street
+// sweep (r03, kernel ms): never 0.72, 256 0.65, 768 0.59, 2048 0.535, 3072 0.53, 4096 0.52, 8192 0.57 — the split
+// costs four queue walks and two barriers per chunk, so only the lists that set the kernel's duration should pay it.
+constexpr uint32_t LONG_TILES_MAX = 2048;
+inline uint32_t long_list_threshold() {
+  static const uint32_t thr = [] {
+    long v = 3072;
+    if (const char* e = getenv("PINGS_BWD_LONG")) v = atol(e);
+    if (v <= 0) return 0xFFFFFFF0u;
+    return (uint32_t)((v + 15) / 16 * 16);
+  }();
+  return thr;
+}
 constexpr uint32_t DEAD_ROW = 0xFFFFFFFFu;
 constexpr int CH = 64;  // rows per first-level chunk of the per-Gaussian sum
 
@@ -431,14 +445,16 @@ struct PopOp {
 // l % G of pixel pp0 + l / G (records are replicated over the groups by the caller).  Per pixel the arithmetic is the
 // one-pixel form's, op for op; a lane's 16 sums run over its group's pixels and the groups are added at the end
 // (fixed order: deterministic).
-template <int MODE, int G>
-__device__ inline void scan_pixels(float4 (*sPix)[4], int lane, int take, int e, int min_e, const float4& a,
+// Pixels [pix0, pix0 + NPIX) of the quadrant: all 64 for a wave that owns the quadrant, 16 (two pixel rows) for each of
+// the four waves that share a long-list quadrant.
+template <int MODE, int G, int NPIX>
+__device__ inline void scan_pixels(float4 (*sPix)[4], int lane, int pix0, int e, int min_e, const float4& a,
                                    const float4& b, const float4& c, const float4& nn, float (&v)[16] STATS_PARAMS) {
   constexpr int NG = 64 / G;
   const int grp = lane / G;
   const float zlo = a.w - b.w, zhi = a.w + b.w;
-  for (int pp0 = 0; pp0 < 64; pp0 += NG) {
-    const int pp = pp0 + grp;
+  for (int pp0 = 0; pp0 < NPIX; pp0 += NG) {
+    const int pp = pix0 + pp0 + grp;
     const float4 s0 = sPix[pp][0];
     const int last_p = (int)__float_as_uint(s0.z);
     if (!__any(last_p > min_e)) {                      // these pixels had stopped before the chunk's first record
@@ -537,20 +553,44 @@ __device__ inline void scan_pixels(float4 (*sPix)[4], int lane, int take, int e,
 __device__ unsigned long long g_bwd_stats[8];
 #endif
 
+// Workgroups of four waves.  A tile of ordinary length takes one workgroup, wave w = quadrant w.  A LONG tile (largest
+// per-pixel contributor count >= the long-list threshold: the first *n_long entries of the descending tile order)
+// takes four workgroups, one per quadrant, whose four waves share the quadrant — 16 pixels each, all walking the same
+// chunks; a record's four partial rows are added in LDS (wave order: deterministic).  With one wave per quadrant
+// throughout, the launch waited for the few waves with the longest lists (C3 street: longest wave 59 chunks, about
+// 0.6 of the kernel's 0.70 ms; mean 4.8).  Long tiles come first in the grid; a second launch for them would run
+// alone on the chip (measured: slower than no split at all).
 template <int MODE>
-__global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
+__global__ __launch_bounds__(256) void blend_bwd_scan_kernel(
     BParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_depth, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dnormal, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
     const uint8_t* __restrict__ qmask, const uint32_t* __restrict__ cidx, float* __restrict__ rows,
-    const uint32_t* __restrict__ tile_order) {
-  __shared__ float4 sPix[64][4];  // {T, R, last, coefT} {gC0, gC1, gC2, gD} {gN0, gN1, gN2, px} {py, rx, ry, -}
-  __shared__ int sQe[128];        // queue of relevant list entries, back to front
-  __shared__ uint32_t sQs[128];   // their instance slots
+    const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ n_long) {
+  // pixel state, per quadrant: {T, R, last, coefT} {gC0, gC1, gC2, gD} {gN0, gN1, gN2, px} {py, rx, ry, -}
+  // ordinary tile: four quadrants x 64 pixels x 4; long tile: the first quarter + the waves' partial rows of a chunk
+  __shared__ float4 sBuf[256 + 1024];
+  __shared__ int sQeAll[4][128];        // per wave: queue of relevant list entries, back to front
+  __shared__ uint32_t sQsAll[4][128];   // their instance slots
 
-  const int lane = threadIdx.x;
-  const int tile = (int)tile_order[blockIdx.x >> 2], q = blockIdx.x & 3;
+  const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+  int* sQe = sQeAll[wv];
+  uint32_t* sQs = sQsAll[wv];
+  const uint32_t nl = *n_long;
+  const bool lng = blockIdx.x < 4u * nl;
+  int tile, q;
+  if (lng) {
+    tile = (int)tile_order[blockIdx.x >> 2];
+    q = (int)(blockIdx.x & 3);
+  } else {
+    const uint32_t ti = nl + (blockIdx.x - 4u * nl);
+    if (ti >= (uint32_t)(p.gx * p.gy)) return;
+    tile = (int)tile_order[ti];
+    q = wv;
+  }
+  float4 (*sPix)[4] = reinterpret_cast<float4 (*)[4]>(sBuf + (lng ? 0 : 256 * wv));
+  float (*sV)[16][64] = reinterpret_cast<float (*)[16][64]>(sBuf + 256);   // [wave][term][record]: 16 KB
   const int tx = tile % p.gx, ty = tile / p.gx;
   const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
   const int pix_y = ty * TILE + 8 * (q >> 1) + (lane >> 3);
@@ -603,6 +643,7 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
   uint32_t m = last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if (lng) __syncthreads();   // every wave wrote the whole quadrant's state (identical values) before any updates it
   int pos = (int)m;  // list entries [0, pos) can matter to this quadrant
   if (pos == 0) return;
   const uint2 range = ranges[tile];
@@ -665,15 +706,40 @@ __global__ __launch_bounds__(64) void blend_bwd_scan_kernel(
     // Chunks that hold at most 16 / 32 records (short lists: a quadrant of a mapping view sees ~20 relevant records)
     // put four / two pixels on the wave at once: lane l works on record l % G for pixel pp0 + l / G.  Measured before
     // this split on the bench's mapping view: 21 records per chunk, 6.9 valid lanes of 64 per pixel iteration.
-    if (take <= 16) scan_pixels<MODE, 16>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
-    else if (take <= 32) scan_pixels<MODE, 32>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
-    else scan_pixels<MODE, 64>(sPix, lane, take, e, min_e, a, b, c, nn, v STATS_ARGS);
-    if (act && gl == lane) {                           // every group holds the same sums: the first one stores
-      float4* dst = reinterpret_cast<float4*>(rows) + (size_t)row * 4;
-      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-      dst[2] = make_float4(v[8], v[9], v[10], v[11]);
-      dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+    if (lng) {
+      if (take <= 16) scan_pixels<MODE, 16, 16>(sPix, lane, 16 * wv, e, min_e, a, b, c, nn, v STATS_ARGS);
+      else if (take <= 32) scan_pixels<MODE, 32, 16>(sPix, lane, 16 * wv, e, min_e, a, b, c, nn, v STATS_ARGS);
+      else scan_pixels<MODE, 64, 16>(sPix, lane, 16 * wv, e, min_e, a, b, c, nn, v STATS_ARGS);
+    } else {
+      if (take <= 16) scan_pixels<MODE, 16, 64>(sPix, lane, 0, e, min_e, a, b, c, nn, v STATS_ARGS);
+      else if (take <= 32) scan_pixels<MODE, 32, 64>(sPix, lane, 0, e, min_e, a, b, c, nn, v STATS_ARGS);
+      else scan_pixels<MODE, 64, 64>(sPix, lane, 0, e, min_e, a, b, c, nn, v STATS_ARGS);
+    }
+    float4* dst = reinterpret_cast<float4*>(rows) + (size_t)row * 4;
+    if (!lng) {
+      if (act && gl == lane) {                         // every group holds the same sums: the first one stores
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+        dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+      }
+    } else {
+      // the four waves' sums over their 16 pixels each meet in LDS; wave w adds and stores quarter w of the row
+      if (gl == lane) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sV[wv][k][lane] = v[k];
+      }
+      __syncthreads();
+      if (act && gl == lane) {
+        float o4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 4 * wv + u;
+          o4[u] = ((sV[0][k][lane] + sV[1][k][lane]) + sV[2][k][lane]) + sV[3][k][lane];
+        }
+        dst[wv] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+      __syncthreads();                                 // the next chunk overwrites sV
     }
   }
 #ifdef PINGS_BWD_STATS
@@ -1109,18 +1175,24 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
     hipLaunchKernelGGL(tile_max_contrib_kernel, dim3(num_tiles), dim3(64), 0, st, bp.W, bp.H, bp.gx, im.n_contrib,
                        bs.tile_work);
     PINGS_LAUNCH_CHECK();
-    if (int e = launch_tile_order(bs.tile_work, num_tiles, bs.tile_order + num_tiles, st)) return e;
+    if (int e = launch_tile_order(bs.tile_work, num_tiles, bs.tile_order + num_tiles, st,
+                                  bs.tile_order + 2 * (size_t)num_tiles, long_list_threshold(), LONG_TILES_MAX))
+      return e;
   }
   if (I > 0 && scan_mode) {
     pings::prof::Scope ps("blend_bwd", st);
-    if (s->mode == PINGS_RASTER_SURFEL)
-      hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_SURFEL>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
-                         bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
-                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows, bs.tile_order + num_tiles);
-    else
-      hipLaunchKernelGGL((blend_bwd_scan_kernel<MODE_3DGS>), dim3(4 * num_tiles), dim3(64), 0, st, bp, bs.ranges,
-                         bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,
-                         dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows, bs.tile_order + num_tiles);
+    // one workgroup per ordinary tile, four per long tile (their number lives on the device: the grid is sized for
+    // the cap, workgroups past the last tile leave at once)
+    const uint32_t* order = bs.tile_order + num_tiles;
+    const uint32_t* n_long = bs.tile_order + 2 * (size_t)num_tiles;
+    const unsigned grid_s = (unsigned)(num_tiles + 3 * std::min<long long>(num_tiles, LONG_TILES_MAX));
+#define PINGS_BWD_SCAN(M)                                                                                             \
+  hipLaunchKernelGGL((blend_bwd_scan_kernel<M>), dim3(grid_s), dim3(256), 0, st, bp, bs.ranges,                       \
+                     bs.point_list, gs.rec, bs.gval, im.final_T, im.n_contrib, out_depth, dL_dcolor, dL_dnormal,     \
+                     dL_ddepth, dL_dalpha, bs.inst_qmask, bw.cidx, bw.rows, order, n_long)
+    if (s->mode == PINGS_RASTER_SURFEL) PINGS_BWD_SCAN(MODE_SURFEL);
+    else PINGS_BWD_SCAN(MODE_3DGS);
+#undef PINGS_BWD_SCAN
     PINGS_LAUNCH_CHECK();
   } else if (I > 0) {
     pings::prof::Scope ps("blend_bwd", st);

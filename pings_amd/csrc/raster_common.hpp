@@ -127,7 +127,9 @@ struct ImageState {
 uint32_t blend_segment_entries();
 GeomState carve_geom(void* blob, int P, int num_tiles);
 // tile_order[i] = i-th tile in descending `work` (ties in any order: scheduling only, results do not depend on it)
-int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st);
+// n_long (optional): receives min(number of tiles with work >= long_thr, long_max) — they lead the order
+int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st, uint32_t* n_long = nullptr,
+                      uint32_t long_thr = 0, uint32_t long_max = 0);
 int occlusion_buckets(int num_tiles);
 BinState carve_binning(void* blob, int64_t I, int num_tiles);
 ImageState carve_image(void* blob, int W, int H);

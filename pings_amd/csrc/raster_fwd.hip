@@ -122,7 +122,7 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   b.tile_key_sorted = c.take<uint32_t>(n);
   b.gval = c.take<uint32_t>(n);
   b.slot_val = c.take<uint32_t>(n);
-  b.tile_order = c.take<uint32_t>(2 * (size_t)num_tiles);
+  b.tile_order = c.take<uint32_t>(2 * (size_t)num_tiles + 4);   // + the backward pass' long-list tile count
   b.tile_work = c.take<uint32_t>((size_t)num_tiles);
   // units of SEG entries for lists beyond 2 SEG: at most I / SEG + I / (2 SEG) of them
   {
@@ -800,7 +800,8 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int gx, int nb,
 // run on an otherwise idle chip.  Dispatching tiles in descending work order fills the tail with short ones.
 // One workgroup: counting sort of the tiles by min(work / 16, 1023), descending.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ work, int num_tiles,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t* __restrict__ n_long,
+                                                          uint32_t long_thr, uint32_t long_max) {
   __shared__ uint32_t hist[1024];
   __shared__ uint32_t base[1024];
   const int tid = threadIdx.x;
@@ -823,6 +824,12 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
   hist[1023 - tid] = excl;   // hist[bin] = first output position of the bin
   __syncthreads();
   for (int t = tid; t < num_tiles; t += 1024) order[atomicAdd(&hist[min(work[t] >> 4, 1023u)], 1u)] = (uint32_t)t;
+  // tiles with work >= long_thr (a multiple of 16: whole bins) are the first entries of the order: their number
+  if (n_long && tid == 0) {
+    const uint32_t bin = min(long_thr >> 4, 1023u);
+    const uint32_t cnt = bin == 0u ? (uint32_t)num_tiles : base[1023 - bin];   // inclusive count of the bins >= bin
+    *n_long = min(cnt, long_max);
+  }
 }
 
 __global__ __launch_bounds__(256) void range_len_kernel(const uint2* __restrict__ ranges, int num_tiles,
@@ -831,8 +838,9 @@ __global__ __launch_bounds__(256) void range_len_kernel(const uint2* __restrict_
   if (t < num_tiles) work[t] = ranges[t].y - ranges[t].x;
 }
 
-int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st) {
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, work, num_tiles, order);
+int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st, uint32_t* n_long,
+                      uint32_t long_thr, uint32_t long_max) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, work, num_tiles, order, n_long, long_thr, long_max);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
