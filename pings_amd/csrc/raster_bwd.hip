@@ -1109,8 +1109,10 @@ PINGS_API int pings_raster_backward(const pings_raster_settings* s, int P, int64
   PINGS_ARG_CHECK(s->mode == PINGS_RASTER_SURFEL || s->mode == PINGS_RASTER_3DGS, "unknown mode");
   PINGS_ARG_CHECK(dL_dtau != nullptr, "null dL_dtau");
   hipStream_t st = pings::as_stream(stream);
-  PINGS_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), st));
-  if (P == 0) return PINGS_OK;
+  if (P == 0) {   // otherwise tau_reduce_kernel writes all six
+    PINGS_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), st));
+    return PINGS_OK;
+  }
   PINGS_ARG_CHECK(P > 0 && means3D && colors && opacities && scales && rotations && geom_blob &&
                       binning_blob && image_blob && out_depth && bwd_blob && dL_dmeans3D &&
                       dL_dmeans2D && dL_dcolors && dL_dopacities && dL_dscales && dL_drotations,

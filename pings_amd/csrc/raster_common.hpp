@@ -86,6 +86,7 @@ struct GeomState {
   uint32_t* nvalid;                         // [1] Gaussians that survived culling (= ranks with a real depth key)
   uint32_t* ds_head;                        // depth sort: header (key range shards, range, overflow flag), then
   uint32_t *ds_cnt, *ds_fill, *ds_off;      //   [DS_NB + blocks] bucket / per-block culled counts, [DS_NB] fill cursors,
+  char* zero_begin; size_t zero_bytes;      // occ_bucket .. stats .. ds_head: the frame's one memset
   size_t ds_words;                          //   [DS_NB + blocks + 1] their exclusive scan; ds_words = memset extent
   uint32_t* ds_idx;                         //   [P] Gaussian ids in bucket order (keys go to depth_key_sorted)
   unsigned long long* stats;                // [2] pairs before occlusion culling, visible Gaussians

@@ -90,16 +90,19 @@ GeomState carve_geom(void* blob, int P, int num_tiles) {
   g.tiles_sorted = c.take<uint32_t>(n);
   g.offsets_sorted = c.take<uint32_t>(n);
   g.occ_nb = occlusion_buckets((int)nt);
+  // occ_bucket, stats and ds_head start every frame at zero: adjacent, ONE memset (zero_begin .. zero_end)
   g.occ_bucket = c.take<uint32_t>(nt * (size_t)g.occ_nb);
-  g.occ_bsat = c.take<uint16_t>(nt);
-  g.nvalid = c.take<uint32_t>(1);
+  g.stats = c.take<unsigned long long>(3 * 256);  // sharded {pairs before culling, visible Gaussians, kept pairs}
   const size_t nblk = (n + 255) / 256;                  // workgroups of the per-Gaussian kernels
-  g.ds_words = DS_HEAD + (size_t)DS_NB + nblk;          // header, counts (+ per-block culled): one memset
+  g.ds_words = DS_HEAD + (size_t)DS_NB + nblk;          // header, counts (+ per-block culled)
   g.ds_head = c.take<uint32_t>(g.ds_words);
   g.ds_cnt = g.ds_head ? g.ds_head + DS_HEAD : nullptr;
+  g.zero_begin = reinterpret_cast<char*>(g.occ_bucket);
+  g.zero_bytes = g.ds_head ? (size_t)(reinterpret_cast<char*>(g.ds_head + g.ds_words) - g.zero_begin) : 0;
+  g.occ_bsat = c.take<uint16_t>(nt);
+  g.nvalid = c.take<uint32_t>(1);
   g.ds_off = c.take<uint32_t>((size_t)DS_NB + nblk + 1);
   g.ds_idx = c.take<uint32_t>(n);
-  g.stats = c.take<unsigned long long>(3 * 256);  // sharded {pairs before culling, visible Gaussians, kept pairs}
   g.summary = c.take<FrameSummary>(1);            // what the frame's one read-back fetches
   g.temp_bytes = sort_temp_bytes((int64_t)n);
   g.temp = c.take<char>(g.temp_bytes);
@@ -112,10 +115,11 @@ BinState carve_binning(void* blob, int64_t I, int num_tiles) {
   BinState b;
   const size_t n = (size_t)(I > 0 ? I : 1);
   b.point_list = c.take<uint32_t>(n);
+  // ranges, inst_w, inst_qmask (and inst_cnt, 3DGS) start at zero: adjacent, ONE memset from `ranges`
   b.ranges = c.take<uint2>((size_t)num_tiles);
   b.inst_w = c.take<float>(n + 1);
-  b.inst_cnt = c.take<uint32_t>(n);
   b.inst_qmask = c.take<uint8_t>(n + 1);
+  b.inst_cnt = c.take<uint32_t>(n);
   b.inst_wq = c.take<float>(4 * n);
   b.inst_cntq = c.take<uint32_t>(4 * n);
   b.tile_key = c.take<uint32_t>(n);
@@ -2047,7 +2051,10 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
   AuxPtrs aux;
   for (int i = 0; i < 8; ++i) aux.p[i] = i < aux_words ? aux_dev[i] : nullptr;
   uint32_t total = 0;
-  for (;;) {
+  // the occlusion budget, the frame statistics and the depth-sort header in one clear (adjacent in the blob); a retry
+  // (depth-bucket overflow) clears again what it reuses
+  PINGS_HIP_CHECK(hipMemsetAsync(gs.zero_begin, 0, gs.zero_bytes, st));
+  for (int attempt = 0;; ++attempt) {
     size_t tb = gs.temp_bytes;
     if (library_sort) {
       pings::prof::Scope ps("depth_sort", st);
@@ -2059,7 +2066,7 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
       PINGS_LAUNCH_CHECK();
     } else {
       pings::prof::Scope ps("depth_sort", st);
-      PINGS_HIP_CHECK(hipMemsetAsync(gs.ds_head, 0, sizeof(uint32_t) * gs.ds_words, st));
+      if (attempt > 0) PINGS_HIP_CHECK(hipMemsetAsync(gs.ds_head, 0, sizeof(uint32_t) * gs.ds_words, st));
       hipLaunchKernelGGL(ds_minmax_kernel, dim3(std::min(pings::ceil_div(P, 256), 512)), block, 0, st, P,
                          gs.depth_key, gs.ds_head);
       PINGS_LAUNCH_CHECK();
@@ -2079,7 +2086,8 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
     if (occlusion) {
       {
         pings::prof::Scope ps("occl_setup", st);
-        PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bucket, 0, sizeof(uint32_t) * (size_t)num_tiles * gs.occ_nb, st));
+        if (attempt > 0)
+          PINGS_HIP_CHECK(hipMemsetAsync(gs.occ_bucket, 0, sizeof(uint32_t) * (size_t)num_tiles * gs.occ_nb, st));
       }
       {
         pings::prof::Scope ps("occl_budget", st);
@@ -2099,7 +2107,7 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
     }
     {
       pings::prof::Scope ps("tile_count_scan", st);
-      PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 3 * STAT_SHARDS * sizeof(unsigned long long), st));
+      if (attempt > 0) PINGS_HIP_CHECK(hipMemsetAsync(gs.stats, 0, 3 * STAT_SHARDS * sizeof(unsigned long long), st));
       hipLaunchKernelGGL(count_kept_kernel, grid, block, 0, st, P, kp.gx, gs.occ_nb, gs.gidx_sorted, gs.rect,
                          gs.occ_bsat, gs.nvalid, gs.tiles_sorted, gs.stats);
       PINGS_LAUNCH_CHECK();
@@ -2162,7 +2170,14 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   BinState bs = carve_binning(binning_blob, I, num_tiles);
   ImageState im = carve_image(image_blob, kp.W, kp.H);
 
-  PINGS_HIP_CHECK(hipMemsetAsync(bs.ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
+  {
+    // tile ranges, per-instance weights and quadrant masks (3DGS: contributor counts too) in one clear
+    const char* z0 = reinterpret_cast<const char*>(bs.ranges);
+    const char* z1 = I > 0 ? (s->mode == PINGS_RASTER_3DGS ? reinterpret_cast<const char*>(bs.inst_cnt + I)
+                                                             : reinterpret_cast<const char*>(bs.inst_qmask + I + 1))
+                           : reinterpret_cast<const char*>(bs.ranges + num_tiles);
+    PINGS_HIP_CHECK(hipMemsetAsync(bs.ranges, 0, (size_t)(z1 - z0), st));
+  }
   if (I > 0) {
     // tile ids fit 16 bits for every image up to 4096x4096: a 2-byte key cuts the sort traffic by a quarter
     const bool k16 = num_tiles <= 65536;
@@ -2219,12 +2234,7 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   // PINGS_BLEND_PPL = 1 | 2 selects the workgroup-per-tile kernel with that many pixels per lane (A/B runs, tests)
   int ppl = 0;
   if (const char* e = getenv("PINGS_BLEND_PPL")) ppl = atoi(e);
-  if (I > 0 && (ppl == 1 || ppl == 2)) {  // the workgroup-per-tile kernels accumulate into zeroed per-instance sums
-    PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));
-    PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));
-    if (s->mode == PINGS_RASTER_3DGS)
-      PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st));
-  }
+  // (the per-instance sums the workgroup-per-tile and wave-per-tile kernels accumulate into were cleared with `ranges`)
   // exact per-quadrant masks are needed iff the backward pass of this view will run the Gaussian-per-lane kernel
   // (same predicate as pings_raster_backward: footprint class, PINGS_BLEND_BWD override); they only cost something
   // in the 2-pixels-per-lane forward
@@ -2273,9 +2283,6 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   const bool tile_wave = (ppl == 4) || (ppl == 0 && footprint_class == 2 && !want_qmask);
 #define PINGS_BLEND_FWD_TILE(M)                                                                        \
   do {                                                                                                 \
-    if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_w, 0, sizeof(float) * ((size_t)I + 1), st));     \
-    if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_qmask, 0, (size_t)I + 1, st));                   \
-    if (I > 0 && M == MODE_3DGS) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_cnt, 0, sizeof(uint32_t) * (size_t)I, st)); \
     hipLaunchKernelGGL((blend_fwd_tile_kernel<M>), dim3(num_tiles), dim3(64), 0, st, kp, bs.ranges,     \
                        bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
                        im.final_T, im.n_contrib, bs.inst_w, bs.inst_cnt, bs.tile_order);               \
