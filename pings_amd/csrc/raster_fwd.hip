@@ -583,7 +583,17 @@ __global__ __launch_bounds__(256) void ds_rank_kernel(const uint32_t* __restrict
     return;
   }
   uint32_t rank = 0u;
-  for (uint32_t t = lo; t < hi; ++t) {
+  uint32_t t = lo;
+  // eight bucket mates per round trip: a crowded bucket (a wall of surfels at one depth: hundreds of mates) made this
+  // loop one dependent load latency per mate
+  for (; t + 8u <= hi; t += 8u) {
+    uint32_t kt[8], it[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { kt[u] = tmp_key[t + u]; it[u] = tmp_idx[t + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rank += (kt[u] < k || (kt[u] == k && it[u] < id)) ? 1u : 0u;
+  }
+  for (; t < hi; ++t) {
     const uint32_t kt = tmp_key[t], it = tmp_idx[t];
     rank += (kt < k || (kt == k && it < id)) ? 1u : 0u;
   }
