@@ -83,7 +83,7 @@ def pmc_traffic(stage, workload=None):
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
         files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs
-                       if f.endswith("pmc_traffic.json") and not f.startswith("sdf_"))
+                       if f.endswith("pmc_traffic.json") and not f.startswith(("sdf_", "ssim_")))
         if not files:
             return None, None, None
         data = json.load(open(files[-1]))

@@ -36,3 +36,15 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_headline_pmc_summary_is_found_next_to_the_other_summaries():
+    """bench.py attaches the committed PMC figures of the headline workload to its roofline; the SSIM / SDF summaries that
+    live in the same directory must not shadow it (they did once: the line fell back to "bound": "hbm")."""
+    import sys
+
+    sys.path.insert(0, str(PROFILES.parent))
+    import bench
+
+    traffic, src, valu = bench.pmc_traffic("blend_bwd", dict(gaussians=1_000_000, width=1920, height=1080, mode="surfel"))
+    assert traffic and valu and src.endswith("pmc_traffic.json") and "ssim" not in src and "sdf" not in src
