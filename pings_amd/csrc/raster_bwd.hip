@@ -47,13 +47,10 @@ constexpr int BATCH = 64;
 // costs four queue walks and two barriers per chunk, so only the lists that set the kernel's duration should pay it.
 constexpr uint32_t LONG_TILES_MAX = 2048;
 inline uint32_t long_list_threshold() {
-  static const uint32_t thr = [] {
-    long v = 3072;
-    if (const char* e = getenv("PINGS_BWD_LONG")) v = atol(e);
-    if (v <= 0) return 0xFFFFFFF0u;
-    return (uint32_t)((v + 15) / 16 * 16);
-  }();
-  return thr;
+  long v = 3072;
+  if (const char* e = getenv("PINGS_BWD_LONG")) v = atol(e);   // read per call: tests switch it
+  if (v <= 0) return 0xFFFFFFF0u;
+  return (uint32_t)((v + 15) / 16 * 16);
 }
 constexpr uint32_t DEAD_ROW = 0xFFFFFFFFu;
 constexpr int CH = 64;  // rows per first-level chunk of the per-Gaussian sum

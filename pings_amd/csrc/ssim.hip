@@ -25,6 +25,20 @@ constexpr int INP = IN + 1;       // padded LDS row
 constexpr int NT = 256;
 constexpr int PERSISTENT_WGS = 256 * 3;   // three workgroups per CU fit by LDS (42 KB each)
 
+// Which tiles a persistent workgroup walks.  Workgroups b and b + 8 share an XCD and with it an L2 (observed dispatch,
+// MI355X_MICROARCH.md: a speed matter only); tiles are numbered row-major.  Giving every XCD label a contiguous band
+// of tiles keeps neighbouring tiles — whose 42 x 42 halo tiles overlap by 5 pixels on every side, 1.72x the bytes of
+// the image — in ONE L2; dealt round-robin (tile t to workgroup t % grid) every neighbour sat behind a different L2
+// and the overlap came from HBM again (PMC, r03: forward 96.5 MB fetched for 49.8 MB of images).
+struct TileWalk { long long first, end, step; };
+__device__ inline TileWalk tile_walk(long long ntiles) {
+  const long long g = gridDim.x, b = blockIdx.x;
+  if ((g & 7) != 0 || ntiles < 8 * 8) return {b, ntiles, g};
+  const long long band = (ntiles + 7) / 8, lo = (b & 7) * band;
+  const long long hi = lo + band < ntiles ? lo + band : ntiles;
+  return {lo + (b >> 3), hi, g >> 3};
+}
+
 // exp(-(k-5)^2 / (2*1.5^2)) / sum, k = 0..10, rounded to fp32.
 __device__ __constant__ float kWin[11] = {
     0.00102838012f, 0.00759875821f, 0.0360007733f, 0.109360687f, 0.213005528f, 0.266011715f,
@@ -70,8 +84,9 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
       rb[u] = in ? img2[off + (size_t)gy * W + gx] : 0.f;
     }
   };
-  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  const TileWalk tw = tile_walk(ntiles);
+  if (tw.first < tw.end) fetch(tw.first);
+  for (long long t = tw.first; t < tw.end; t += tw.step) {
     const int x0 = (int)(t % GX) * TS, y0 = (int)((t / GX) % GY) * TS;
     const size_t plane_off = (size_t)(t / ((long long)GX * GY)) * H * W;
 #pragma unroll
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
       }
     }
     __syncthreads();
-    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+    if (t + tw.step < tw.end) fetch(t + tw.step);
 
     // horizontal pass: 42 rows x 32 cols, five statistics each.  A thread owns FOUR adjacent output columns of a row:
     // the 14 inputs they share are read from LDS once (7 reads per output and image instead of 22; the pass was
@@ -231,8 +246,9 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
         r2[u] = in ? dm_dsigma12[o] : 0.f;
       }
     };
-    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.first < tw.end) fetch(tw.first);
+  for (long long t = tw.first; t < tw.end; t += tw.step) {
     const int x0 = (int)(t % GX) * TS, y0 = (int)((t / GX) % GY) * TS;
     const size_t plane_off = (size_t)(t / ((long long)GX * GY)) * H * W;
 #pragma unroll
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
       }
     }
     __syncthreads();
-    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+    if (t + tw.step < tw.end) fetch(t + tw.step);
     // four adjacent outputs per thread in both passes (see ssim_fwd_kernel): same taps in the same order, 3.1x fewer
     // LDS reads
     for (int i = tid; i < IN * (TS / 4); i += NT) {

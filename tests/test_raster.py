@@ -782,3 +782,45 @@ def test_long_lists_blended_in_parallel_segments(mode, monkeypatch):
         assert rel_err(a, b) <= 2e-4
     o, *_ = _oracle(sc, torch.float64, mode, False)
     assert rel_err(out_s[0], o["color"]) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["surfel", "3dgs"])
+def test_long_tiles_share_their_quadrants_between_four_waves(mode, monkeypatch):
+    """Tiles with long lists get four workgroups in the Gaussian-per-lane backward, each quadrant shared by four waves
+    with 16 pixels each (csrc/raster_bwd.hip, blend_bwd_scan_kernel).  Forced here for every tile (threshold 16) and for
+    the tiles above the median list length (a frame with both kinds of workgroup): all gradients equal those of the
+    one-wave-per-quadrant walk up to the summation order of a row (1e-5) and match the fp64 oracle's gate."""
+    from pings_amd import rasterizer as hr
+
+    W, H = 160, 96
+    sc = make_scene(5000, W, H, seed=93, surfel=(mode == "surfel"), smin=0.05, smax=0.5)
+    sc["op"] = sc["op"] * 0.25                                  # translucent: lists are walked deep
+
+    def run(thr):
+        monkeypatch.setenv("PINGS_BWD_LONG", thr)
+        monkeypatch.setenv("PINGS_BLEND_PPL", "-1")
+        monkeypatch.setenv("PINGS_BLEND_BWD", "scan")
+        hs = hip_settings(sc, mode, False, 1.0)
+        rast = (hr.SurfelGaussianRasterizer if mode == "surfel" else hr.GS3DGaussianRasterizer)(hs)
+        leaves = [sc[k].to(torch.float32).cuda().contiguous().requires_grad_(True)
+                  for k in ("means", "col", "op", "scales", "rot")]
+        th = torch.zeros(3, device="cuda", requires_grad=True)
+        rh = torch.zeros(3, device="cuda", requires_grad=True)
+        out = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), colors_precomp=leaves[1],
+                   opacities=leaves[2], scales=leaves[3], rotations=leaves[4], theta=th, rho=rh)
+        imgs = [t for t in out if t.is_floating_point() and t.dim() == 3]
+        gg = torch.Generator(device="cuda").manual_seed(9)
+        torch.autograd.backward(imgs, [torch.randn(t.shape, generator=gg, device="cuda") for t in imgs])
+        fs, _, _ = hr._forward(rast._prepared(), *[t.detach() for t in leaves])
+        _, _, _, nc = hr.debug_lists(fs)
+        return [t.grad for t in leaves] + [th.grad, rh.grad], nc
+
+    g_one, nc = run("0")
+    work = nc.view(H // 16, 16, W // 16, 16).permute(0, 2, 1, 3).reshape(-1, 256).max(1).values
+    assert int(work.min()) >= 16 and int(work.max()) > 4 * 64, (int(work.min()), int(work.max()))
+    median = int(work.float().median())
+    for thr in ("16", str(median)):
+        g_four, _ = run(thr)
+        for a, b in zip(g_four, g_one):
+            assert rel_err(a, b) <= 1e-5, thr
