@@ -1177,27 +1177,42 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
   bool done = !inside;
 
   // window being fetched: slot, Gaussian id, first two record quads of list entry base + lane
-  uint32_t f_slot = 0, f_g = 0;
-  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
-  bool f_ok = false;
-  auto fetch = [&](int base) {
+  // two-stage fetch pipeline (list entry -> Gaussian id | id -> whole record), see blend_fwd_seg_kernel
+  uint32_t f_slot = 0, f_g = 0, n_slot = 0, n_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a, f_c = f_a, f_d = f_a;
+  bool f_ok = false, n_ok = false;
+  auto fetch_ids = [&](int base) {
     const int e = base + lane;
-    f_ok = e < todo;
-    if (f_ok) {
-      f_slot = point_list[range.x + e];
-      f_g = gval[f_slot];
-      f_a = rec[4 * (size_t)f_g + 0];
-      f_b = rec[4 * (size_t)f_g + 1];
+    n_ok = e < todo;
+    if (n_ok) {
+      n_slot = point_list[range.x + e];
+      n_g = gval[n_slot];
     }
   };
-  if (todo > 0 && !__all(done)) fetch(0);
+  auto fetch_records = [&]() {
+    f_slot = n_slot; f_g = n_g; f_ok = n_ok;
+    if (f_ok) {
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+      f_c = rec[4 * (size_t)f_g + 2];
+      if (MODE == MODE_SURFEL) f_d = rec[4 * (size_t)f_g + 3];
+    }
+  };
+  if (todo > 0 && !__all(done)) {
+    fetch_ids(0);
+    fetch_records();
+    if (64 < todo) fetch_ids(64); else n_ok = false;
+  }
 
   for (int base = 0; base < todo; base += 64) {
     if (__all(done)) break;
-    const uint32_t slot = f_slot, g = f_g;
-    const float4 ra = f_a, rb = f_b;
+    const uint32_t slot = f_slot;
+    const float4 ra = f_a, rb = f_b, rc = f_c, rd = f_d;
     const bool ok = f_ok;
-    if (base + 64 < todo) fetch(base + 64);               // in flight while this window is blended
+    if (base + 64 < todo) {                                // in flight while this window is blended
+      fetch_records();
+      if (base + 128 < todo) fetch_ids(base + 128); else n_ok = false;
+    }
     bool rel = false;
     if (ok) {
       const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
@@ -1209,8 +1224,8 @@ __global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
       const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
       sA[at] = ra;
       sB[at] = rb;
-      sC[at] = rec[4 * (size_t)g + 2];
-      if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+      sC[at] = rc;
+      if (MODE == MODE_SURFEL) sD[at] = rd;
       sSlot[at] = slot;
       sE[at] = base + lane;
     }
@@ -1419,27 +1434,47 @@ __global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f;
   uint32_t last = 0;
 
-  uint32_t f_slot = 0, f_g = 0;
-  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
-  bool f_ok = false;
-  auto fetch = [&](int base) {
+  // The fetch of a window is a chain of three dependent loads (list entry -> Gaussian id -> record).  It runs as a
+  // two-stage pipeline: the ids of window k + 2 and the records of window k + 1 are in flight while window k is
+  // blended, so no stage has to cover more than two dependent latencies with one window's work (with the whole chain
+  // one window ahead, the short windows of pass T waited for it).
+  uint32_t f_slot = 0, f_g = 0, n_slot = 0, n_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a, f_c = f_a, f_d = f_a;
+  bool f_ok = false, n_ok = false;
+  auto fetch_ids = [&](int base) {       // stage 1: list entry -> Gaussian id
     const int e = base + lane;
-    f_ok = e < e_hi;
-    if (f_ok) {
-      f_slot = point_list[range.x + e];
-      f_g = gval[f_slot];
-      f_a = rec[4 * (size_t)f_g + 0];
-      f_b = rec[4 * (size_t)f_g + 1];
+    n_ok = e < e_hi;
+    if (n_ok) {
+      n_slot = point_list[range.x + e];
+      n_g = gval[n_slot];
     }
   };
-  if (e_lo < e_hi && !__all(done)) fetch(e_lo);
+  auto fetch_records = [&]() {           // stage 2: the ids that stage 1 brought -> first two record quads
+    f_slot = n_slot; f_g = n_g; f_ok = n_ok;
+    if (f_ok) {
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+      if (PASS == 1) {                   // the other half of the 64-byte record: same cache line, and the blend loop
+        f_c = rec[4 * (size_t)f_g + 2];  // no longer starts with a load of its own
+        if (MODE == MODE_SURFEL) f_d = rec[4 * (size_t)f_g + 3];
+      }
+    }
+  };
+  if (e_lo < e_hi && !__all(done)) {
+    fetch_ids(e_lo);
+    fetch_records();
+    if (e_lo + 64 < e_hi) fetch_ids(e_lo + 64); else n_ok = false;
+  }
 
   for (int base = e_lo; base < e_hi; base += 64) {
     if (__all(done)) break;
-    const uint32_t slot = f_slot, g = f_g;
-    const float4 ra = f_a, rb = f_b;
+    const uint32_t slot = f_slot;
+    const float4 ra = f_a, rb = f_b, rc = f_c, rd = f_d;
     const bool ok = f_ok;
-    if (base + 64 < e_hi) fetch(base + 64);
+    if (base + 64 < e_hi) {
+      fetch_records();
+      if (base + 128 < e_hi) fetch_ids(base + 128); else n_ok = false;
+    }
     bool rel = false;
     if (ok) {
       const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
@@ -1452,8 +1487,8 @@ __global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
       sA[at] = ra;
       sB[at] = rb;
       if (PASS == 1) {
-        sC[at] = rec[4 * (size_t)g + 2];
-        if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+        sC[at] = rc;
+        if (MODE == MODE_SURFEL) sD[at] = rd;
         sSlot[at] = slot;
         sE[at] = base + lane;
       }
@@ -1662,27 +1697,42 @@ __global__ __launch_bounds__(64) void blend_fwd_tile_kernel(
     all_done_lane = all_done_lane && done[k];
   }
 
-  uint32_t f_slot = 0, f_g = 0;
-  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a;
-  bool f_ok = false;
-  auto fetch = [&](int base) {
+  // two-stage fetch pipeline (list entry -> Gaussian id | id -> whole record), see blend_fwd_seg_kernel
+  uint32_t f_slot = 0, f_g = 0, n_slot = 0, n_g = 0;
+  float4 f_a = make_float4(0.f, 0.f, 0.f, 0.f), f_b = f_a, f_c = f_a, f_d = f_a;
+  bool f_ok = false, n_ok = false;
+  auto fetch_ids = [&](int base) {
     const int e = base + lane;
-    f_ok = e < todo;
-    if (f_ok) {
-      f_slot = point_list[range.x + e];
-      f_g = gval[f_slot];
-      f_a = rec[4 * (size_t)f_g + 0];
-      f_b = rec[4 * (size_t)f_g + 1];
+    n_ok = e < todo;
+    if (n_ok) {
+      n_slot = point_list[range.x + e];
+      n_g = gval[n_slot];
     }
   };
-  if (todo > 0 && !__all(all_done_lane)) fetch(0);
+  auto fetch_records = [&]() {
+    f_slot = n_slot; f_g = n_g; f_ok = n_ok;
+    if (f_ok) {
+      f_a = rec[4 * (size_t)f_g + 0];
+      f_b = rec[4 * (size_t)f_g + 1];
+      f_c = rec[4 * (size_t)f_g + 2];
+      if (MODE == MODE_SURFEL) f_d = rec[4 * (size_t)f_g + 3];
+    }
+  };
+  if (todo > 0 && !__all(all_done_lane)) {
+    fetch_ids(0);
+    fetch_records();
+    if (64 < todo) fetch_ids(64); else n_ok = false;
+  }
 
   for (int base = 0; base < todo; base += 64) {
     if (__all(all_done_lane)) break;
-    const uint32_t slot = f_slot, g = f_g;
-    const float4 ra = f_a, rb = f_b;
+    const uint32_t slot = f_slot;
+    const float4 ra = f_a, rb = f_b, rc = f_c, rd = f_d;
     const bool ok = f_ok;
-    if (base + 64 < todo) fetch(base + 64);               // in flight while this window is blended
+    if (base + 64 < todo) {                                // in flight while this window is blended
+      fetch_records();
+      if (base + 128 < todo) fetch_ids(base + 128); else n_ok = false;
+    }
     bool rel = false;
     if (ok) {
       const float thr = 2.f * __logf(255.f * ra.z) + 2e-3f;
@@ -1694,8 +1744,8 @@ __global__ __launch_bounds__(64) void blend_fwd_tile_kernel(
       const int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
       sA[at] = ra;
       sB[at] = rb;
-      sC[at] = rec[4 * (size_t)g + 2];
-      if (MODE == MODE_SURFEL) sD[at] = rec[4 * (size_t)g + 3];
+      sC[at] = rc;
+      if (MODE == MODE_SURFEL) sD[at] = rd;
       sSlot[at] = slot;
       sE[at] = base + lane;
     }
