@@ -643,7 +643,9 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
       xcol[s2] = (row < N && r < IN) ? x[(size_t)row * IN + r] : 0.f;
       gycol[s2] = (row < N && r < OUT) ? gy[(size_t)row * OUT + r] : 0.f;
     }
-    if (t + nwaves < ntiles) fetch_rows(t + nwaves, xn, gn);
+    // unconditional (rows beyond N load nothing): behind a branch the loads' count is unknown to the compiler and the
+    // first use of the column views waits for vmcnt(0), i.e. for this prefetch too
+    fetch_rows(t + nwaves, xn, gn);
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) aB2 += gycol[s2];
     const float one = h == 0 ? 1.f : 0.f;
