@@ -623,6 +623,22 @@ PINGS_API int pings_map_reset_local(int64_t num_points, const float* neural_poin
                                     float local_radius, float sorrounding_radius, void* scratch, uint8_t* local_mask,
                                     uint8_t* sorrounding_mask, int64_t* global2local, int64_t* local_idx,
                                     int64_t* num_local, void* stream);
+/* `NeuralPoints.gather_local_data` (model/neural_gaussians.py:1135-1173) indexes nine per-point tensors with the
+ * boolean surrounding mask, one nonzero + host synchronisation each in torch.  Here:
+ *   pings_mask_rows         rows[<= n] (int64, ascending) = the indices where mask[i] != 0; count_and_last (HOST, two
+ *                           int64): their number and mask[n - 1] (the feature tables carry a padding row that the
+ *                           per-point tensors do not: :1159-1161).  Synchronises `stream` once (polled read-back).
+ *   pings_gather_rows_multi dst_g[i] = src_g[idx[i]] for i < rows_g, all tensors g in ONE launch (any row width). */
+typedef struct pings_gather_job {
+  const void* src;
+  void* dst;
+  int64_t row_bytes;
+  int64_t rows;
+} pings_gather_job;
+PINGS_API size_t pings_mask_rows_scratch_bytes(int64_t n);
+PINGS_API int pings_mask_rows(const uint8_t* mask, int64_t n, void* scratch, int64_t* rows, int64_t* count_and_last,
+                              void* stream);
+PINGS_API int pings_gather_rows_multi(const pings_gather_job* jobs, int njobs, const int64_t* idx, void* stream);
 /* dst[i] = src[idx[i]] / dst[idx[i]] = src[i] for rows of row_bytes bytes (any dtype). */
 PINGS_API int pings_gather_rows(const void* src, int64_t row_bytes, const int64_t* idx, int64_t n, void* dst,
                                 void* stream);

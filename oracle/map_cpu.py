@@ -277,3 +277,26 @@ def recreate_hash(m, sensor_position, sensor_orientation=None, kept_points: bool
     m.buffer_pt_index[slot[keep]] = vals[keep]
     if sensor_position is not None:
         reset_local_map(m, sensor_position, cur_ts)
+
+
+def gather_local_data(m, with_sorroundings: bool = True):
+    """model/neural_gaussians.py:1135-1173: the local tensors as they are; the ring around the local map by boolean
+    indexing with `sorrounding_mask` (per-point tensors with mask[:-1], the feature tables with the whole mask)."""
+    data = {
+        "position": m.local_neural_points, "orientation": m.local_point_orientations, "color": m.local_point_colors,
+        "geo_feature": m.local_geo_features, "color_feature": m.local_color_features, "resolution": m.resolution,
+        "free_mask": m.local_free_gs_mask, "valid_mask": m.local_valid_gs_mask, "stability": m.local_point_certainties,
+    }
+    if not with_sorroundings:
+        return data, None
+    mask = m.sorrounding_mask.bool()
+    a = mask[:-1]
+    sur = {"position": m.neural_points[a], "orientation": m.point_orientations[a], "geo_feature": m.geo_features[mask]}
+    if m.point_colors is not None:
+        sur["color"] = m.point_colors[a]
+        sur["color_feature"] = m.color_features[mask]
+    sur["resolution"] = m.resolution
+    sur["free_mask"] = m.free_gs_mask[a]
+    sur["valid_mask"] = m.valid_gs_mask[a]
+    sur["stability"] = m.point_certainties[a]
+    return data, sur

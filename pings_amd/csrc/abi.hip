@@ -161,6 +161,6 @@ PINGS_API int pings_prof_report(char* buf, size_t cap) {
   return PINGS_OK;
 }
 
-PINGS_API int pings_abi_version(void) { return 5; }
+PINGS_API int pings_abi_version(void) { return 6; }
 
 PINGS_API const char* pings_last_error(void) { return pings::g_err; }

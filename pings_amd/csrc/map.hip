@@ -692,6 +692,110 @@ PINGS_API int pings_gather_rows(const void* src, int64_t row_bytes, const int64_
   return PINGS_OK;
 }
 
+// ---------------------------------------------------------------- gather_local_data (model/neural_gaussians.py:1135-1173)
+namespace {
+struct MaskRows {
+  i64* num;        // [1] rows selected
+  uint32_t* out2;  // [2] {rows selected, mask[n - 1]} for the one read-back
+  char* temp;
+  size_t temp_bytes, total;
+};
+MaskRows carve_mask_rows(void* blob, i64 n) {
+  char* base = reinterpret_cast<char*>(blob);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off = (off + bytes + 255) & ~(size_t)255; return q; };
+  MaskRows m;
+  m.num = reinterpret_cast<i64*>(take(sizeof(i64)));
+  m.out2 = reinterpret_cast<uint32_t*>(take(2 * sizeof(uint32_t)));
+  size_t tb = 0;
+  (void)hipcub::DeviceSelect::Flagged(nullptr, tb, hipcub::CountingInputIterator<i64>(0), (const uint8_t*)nullptr,
+                                      (i64*)nullptr, (i64*)nullptr, (int)(n > 0 ? n : 1));
+  m.temp_bytes = tb;
+  m.temp = take(tb);
+  m.total = off;
+  return m;
+}
+__global__ void mask_tail_kernel(const uint8_t* __restrict__ mask, i64 n, const i64* __restrict__ num,
+                                 uint32_t* __restrict__ out2) {
+  out2[0] = (uint32_t)*num;
+  out2[1] = mask[n - 1] ? 1u : 0u;
+}
+constexpr int MAX_GATHER_JOBS = 16;
+struct GatherJobs {
+  const uint8_t* src[MAX_GATHER_JOBS];
+  uint8_t* dst[MAX_GATHER_JOBS];
+  i64 row_bytes[MAX_GATHER_JOBS];
+  i64 rows[MAX_GATHER_JOBS];
+};
+// blockIdx.y = tensor; rows of 4-byte multiples move as words, the others (bool masks) as bytes
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherJobs j, const i64* __restrict__ idx) {
+  const int g = blockIdx.y;
+  const i64 rb = j.row_bytes[g], n = j.rows[g];
+  const bool words = (rb & 3) == 0 && ((uintptr_t)j.src[g] & 3) == 0 && ((uintptr_t)j.dst[g] & 3) == 0;
+  const i64 stride = (i64)gridDim.x * 256;
+  if (words) {
+    const i64 rw = rb >> 2;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(j.src[g]);
+    uint32_t* d = reinterpret_cast<uint32_t*>(j.dst[g]);
+    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < n * rw; e += stride) {
+      const i64 r = e / rw, c = e - r * rw;
+      d[e] = s[idx[r] * rw + c];
+    }
+  } else {
+    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < n * rb; e += stride) {
+      const i64 r = e / rb, c = e - r * rb;
+      j.dst[g][e] = j.src[g][idx[r] * rb + c];
+    }
+  }
+}
+}  // namespace
+
+PINGS_API size_t pings_mask_rows_scratch_bytes(int64_t n) { return carve_mask_rows(nullptr, n).total; }
+
+PINGS_API int pings_mask_rows(const uint8_t* mask, int64_t n, void* scratch, int64_t* rows, int64_t* count_and_last,
+                              void* stream) {
+  PINGS_ARG_CHECK(n >= 0 && n < (int64_t)0x7FFFFFF0 && count_and_last, "bad arguments");
+  count_and_last[0] = 0; count_and_last[1] = 0;
+  if (n == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(mask && scratch && rows, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  MaskRows m = carve_mask_rows(scratch, n);
+  size_t tb = m.temp_bytes;
+  PINGS_HIP_CHECK(hipcub::DeviceSelect::Flagged(m.temp, tb, hipcub::CountingInputIterator<i64>(0), mask,
+                                                reinterpret_cast<i64*>(rows), m.num, (int)n, st));
+  mask_tail_kernel<<<1, 1, 0, st>>>(mask, n, m.num, m.out2);
+  PINGS_LAUNCH_CHECK();
+  const uint32_t* src[2] = {m.out2, m.out2 + 1};
+  uint32_t got[2] = {0u, 0u};
+  if (int e = pings::host_read_words(src, 2, got, st)) return e;
+  count_and_last[0] = (int64_t)got[0];
+  count_and_last[1] = (int64_t)got[1];
+  return PINGS_OK;
+}
+
+PINGS_API int pings_gather_rows_multi(const pings_gather_job* jobs, int njobs, const int64_t* idx, void* stream) {
+  PINGS_ARG_CHECK(jobs && njobs > 0 && njobs <= MAX_GATHER_JOBS, "1..16 jobs");
+  GatherJobs J;
+  i64 most = 0;
+  for (int g = 0; g < njobs; ++g) {
+    PINGS_ARG_CHECK(jobs[g].row_bytes > 0 && jobs[g].rows >= 0, "bad sizes in job");
+    PINGS_ARG_CHECK(jobs[g].rows == 0 || (jobs[g].src && jobs[g].dst), "null pointer in job");
+    J.src[g] = reinterpret_cast<const uint8_t*>(jobs[g].src);
+    J.dst[g] = reinterpret_cast<uint8_t*>(jobs[g].dst);
+    J.row_bytes[g] = jobs[g].row_bytes;
+    J.rows[g] = jobs[g].rows;
+    const i64 work = jobs[g].rows * ((jobs[g].row_bytes & 3) == 0 ? jobs[g].row_bytes >> 2 : jobs[g].row_bytes);
+    if (work > most) most = work;
+  }
+  if (most == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(idx != nullptr, "null index list");
+  hipStream_t st = pings::as_stream(stream);
+  const i64 nb = (most + 255) / 256;
+  gather_rows_multi_kernel<<<dim3((unsigned)(nb < 4096 ? nb : 4096), (unsigned)njobs), 256, 0, st>>>(J, (const i64*)idx);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
 PINGS_API int pings_scatter_rows(const void* src, int64_t row_bytes, const int64_t* idx, int64_t n, void* dst,
                                  void* stream) {
   PINGS_ARG_CHECK(n >= 0 && row_bytes > 0, "bad sizes");

@@ -30,6 +30,10 @@ _ROW_ATTRS = {  # attribute -> (columns, dtype)
 }
 
 
+class _GatherJob(C.Structure):   # include/pings_hip.h: pings_gather_job
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64), ("rows", C.c_int64)]
+
+
 def _declare(L):
     if getattr(L, "_map_declared", False):
         return
@@ -49,6 +53,12 @@ def _declare(L):
                                         vp, vp, vp, vp, vp, C.POINTER(i64), vp]
     L.pings_voxel_downsample_min_value.restype = C.c_int
     L.pings_voxel_downsample_min_value.argtypes = [vp, vp, i64, f32, vp, vp, C.POINTER(i64), vp]
+    L.pings_mask_rows_scratch_bytes.restype = C.c_size_t
+    L.pings_mask_rows_scratch_bytes.argtypes = [i64]
+    L.pings_mask_rows.restype = C.c_int
+    L.pings_mask_rows.argtypes = [vp, i64, vp, vp, C.POINTER(i64), vp]
+    L.pings_gather_rows_multi.restype = C.c_int
+    L.pings_gather_rows_multi.argtypes = [C.POINTER(_GatherJob), i32, vp, vp]
     L.pings_map_prune_mask.restype = C.c_int
     L.pings_map_prune_mask.argtypes = [i64, vp, i32, vp, vp, f32, f32, vp, vp]
     L.pings_map_adjust.restype = C.c_int
@@ -270,6 +280,74 @@ def assign_local_to_global(m):
         _scatter(L, m.local_color_features.data, lidx, nl + 1, m.color_features)
 
 
+# ------------------------------------------------------------------ gather_local_data (model/neural_gaussians.py:1135-1173)
+def _mask_rows(L, mask: torch.Tensor):
+    """Ascending row indices of a bool / uint8 mask, their number and the mask's last entry: one polled read-back."""
+    mask = mask.contiguous()
+    n = int(mask.shape[0])
+    dev = mask.device
+    rows = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    scratch = torch.empty(L.pings_mask_rows_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    out = (C.c_int64 * 2)(0, 0)
+    _lib.note_sync("mask_rows_count")
+    _lib.check(L.pings_mask_rows(_lib.ptr(_u8(mask)), n, _lib.ptr(scratch), _lib.ptr(rows), out, _lib.stream_ptr(dev)),
+               "pings_mask_rows")
+    return rows, int(out[0]), int(out[1])
+
+
+def _gather_many(L, pairs, idx: torch.Tensor):
+    """[(tensor, rows)] -> [tensor[idx[:rows]]], every tensor in one launch."""
+    outs, jobs = [], (_GatherJob * len(pairs))()
+    keep = []
+    for g, (src, rows) in enumerate(pairs):
+        src = src.detach().contiguous()
+        keep.append(src)
+        row = src.element_size()
+        for d in src.shape[1:]:
+            row *= int(d)
+        out = torch.empty((rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        outs.append(out)
+        jobs[g] = _GatherJob(_lib.ptr(_u8(src)) if src.numel() else None, _lib.ptr(_u8(out)) if rows else None, row, rows)
+    _lib.check(L.pings_gather_rows_multi(jobs, len(pairs), _lib.ptr(idx), _lib.stream_ptr(idx.device)),
+               "pings_gather_rows_multi")
+    return outs
+
+
+def gather_local_data(m, with_sorroundings: bool = True):
+    """`NeuralPoints.gather_local_data` (model/neural_gaussians.py:1135-1173): the local map's tensors as they are and,
+    for the ring around it, every per-point tensor indexed with the boolean surrounding mask.  The reference pays one
+    `nonzero` + host synchronisation per indexed tensor (nine); here the mask becomes a row list once (one polled
+    read-back) and all tensors are gathered by one launch."""
+    data = {
+        "position": m.local_neural_points, "orientation": m.local_point_orientations, "color": m.local_point_colors,
+        "geo_feature": m.local_geo_features, "color_feature": m.local_color_features, "resolution": m.resolution,
+        "free_mask": m.local_free_gs_mask, "valid_mask": m.local_valid_gs_mask, "stability": m.local_point_certainties,
+    }
+    if not with_sorroundings:
+        return data, None
+    _need_device(m.neural_points, "NeuralPoints.gather_local_data")
+    L = _L()
+    mask = m.sorrounding_mask                                    # [n + 1]; the features take its padding entry too
+    n = int(m.neural_points.shape[0])
+    if int(mask.shape[0]) != n + 1:
+        raise _lib.PingsHipError("gather_local_data: sorrounding_mask does not have one entry per point plus one")
+    rows, count, last = _mask_rows(L, mask)
+    k_pts, k_feat = count - last, count                          # mask[:-1] / the whole mask (:1159-1161)
+    names = [("position", m.neural_points, k_pts), ("orientation", m.point_orientations, k_pts),
+             ("geo_feature", m.geo_features, k_feat)]
+    if getattr(m, "point_colors", None) is not None:
+        names += [("color", m.point_colors, k_pts), ("color_feature", m.color_features, k_feat)]
+    names += [("free_mask", m.free_gs_mask, k_pts), ("valid_mask", m.valid_gs_mask, k_pts),
+              ("stability", m.point_certainties, k_pts)]
+    outs = _gather_many(L, [(t, k) for _, t, k in names], rows)
+    sur = {name: o for (name, _, _), o in zip(names, outs)}
+    sur["resolution"] = m.resolution
+    # key order of the reference's dict
+    order = ["position", "orientation", "geo_feature", "color", "color_feature", "resolution", "free_mask", "valid_mask",
+             "stability"]
+    return data, {k: sur[k] for k in order if k in sur}
+
+
 # ------------------------------------------------------------------ loop closure (model/neural_gaussians.py:871-1010)
 def _table_changed(m):
     m._pings_table_gen = getattr(m, "_pings_table_gen", 0) + 1
@@ -411,3 +489,4 @@ def install(neural_points_cls) -> None:
     neural_points_cls.prune_map = prune_map
     neural_points_cls.adjust_map = adjust_map
     neural_points_cls.recreate_hash = recreate_hash
+    neural_points_cls.gather_local_data = gather_local_data

@@ -209,6 +209,87 @@ def test_map_product_path_rejects_host_tensors():
         NM.voxel_down_sample(torch.rand(100, 3), 0.25)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_gather_local_data_oracle_on_the_reference_vectors(golden_dir, name):
+    """The oracle's `gather_local_data` on the map the reference's own vectors lead to: the ring around the local map is
+    the reference's masks applied to the reference's tensors (both stored in the golden file), the features one row
+    longer (padding entry of the mask)."""
+    st = _load(golden_dir, name)
+    m = _run_frames(st, M, "cpu")
+    f = f"f{int(st['frames']) - 1}_"
+    loc, sur = M.gather_local_data(m)
+    mask = st[f + "sorrounding_mask"].astype(bool)
+    _eq(sur["position"], st[f + "neural_points"][mask[:-1]], "surrounding position")
+    _eq(sur["color"], st[f + "point_colors"][mask[:-1]], "surrounding color")
+    _eq(sur["free_mask"], st[f + "free_gs_mask"][mask[:-1]], "surrounding free mask")
+    _eq(sur["geo_feature"], st[f + "geo_features_after"][mask], "surrounding geo features")
+    assert sur["geo_feature"].shape[0] == sur["position"].shape[0] + 1
+    assert loc["position"] is m.local_neural_points and loc["geo_feature"] is m.local_geo_features
+
+
+def _check_gather_local_data(mc, mh, tag):
+    """`gather_local_data` (model/neural_gaussians.py:1135-1173): HIP path (one row list + one gather launch) against
+    the oracle's boolean indexing — every tensor of both dicts bit for bit, same keys in the same order."""
+    from pings_amd import _lib, neural_map as NM
+
+    _lib.sync_counts(reset=True)
+    loc_h, sur_h = NM.gather_local_data(mh)
+    assert _lib.sync_counts(reset=True) == {"mask_rows_count": 1}
+    loc_c, sur_c = M.gather_local_data(mc)
+    assert list(loc_h) == list(loc_c) and list(sur_h) == list(sur_c), (tag, list(sur_h), list(sur_c))
+    for name, d_h, d_c in (("local", loc_h, loc_c), ("surrounding", sur_h, sur_c)):
+        for k in d_c:
+            a, b = d_h[k], d_c[k]
+            if isinstance(b, torch.Tensor):
+                assert a.dtype == b.dtype and torch.equal(a.detach().cpu(), b.detach()), (tag, name, k)
+            else:
+                assert a == b, (tag, name, k)
+    assert sur_h["geo_feature"].shape[0] == sur_h["position"].shape[0] + 1      # the padding row travels with the features
+    only_local, none = NM.gather_local_data(mh, with_sorroundings=False)
+    assert none is None and only_local["position"] is mh.local_neural_points
+
+
+@pytest.mark.gpu
+def test_gather_local_data_with_a_mask_set_by_other_code():
+    """A surrounding mask that other code wrote (padding entry cleared, nothing selected, everything selected): the row
+    counts of the per-point tensors and of the feature tables follow mask[:-1] and the whole mask."""
+    hip = _HipAdapter()
+    g = torch.Generator().manual_seed(5)
+    kw = dict(temporal_local_map_on=False, use_mid_ts=False, range_filter_2d=True, local_map_radius=8.0,
+              sorrounding_map_radius=14.0, diff_travel_dist_local=5.0)
+    mc = M.new_map(100_003, 8, 4, 0.5, **kw)
+    mh = hip.new_map(100_003, 8, 4, 0.5, device="cuda", **kw)
+    mc.travel_dist, mh.travel_dist = torch.zeros(2), torch.zeros(2).cuda()
+    pts = (torch.rand(30_000, 3, generator=g) - 0.5) * torch.tensor([40.0, 40.0, 2.0])
+    cols = torch.rand(30_000, 3, generator=g)
+    M.update(mc, pts, cols, 0)
+    n = mc.neural_points.shape[0]
+    ng, ncol = torch.randn(n + 1, 8, generator=g), torch.randn(n + 1, 4, generator=g)
+    mc.geo_features[:] = ng
+    mc.color_features[:] = ncol
+    hip.update(mh, pts.cuda(), cols.cuda(), 0, new_geo=ng, new_color=ncol)
+    sensor = torch.tensor([1.0, -2.0, 0.0])
+    M.reset_local_map(mc, sensor, 0)
+    hip.reset_local_map(mh, sensor.cuda(), 0)
+    for variant in ("as_reset", "padding_cleared", "none", "all"):
+        mask = mc.sorrounding_mask.clone()
+        if variant == "padding_cleared":
+            mask[-1] = False
+        elif variant == "none":
+            mask[:] = False
+        elif variant == "all":
+            mask[:] = True
+        mc.sorrounding_mask, mh.sorrounding_mask = mask, mask.cuda()
+        from pings_amd import neural_map as NM
+        _, sur_h = NM.gather_local_data(mh)
+        _, sur_c = M.gather_local_data(mc)
+        for k, b in sur_c.items():
+            if isinstance(b, torch.Tensor):
+                assert torch.equal(sur_h[k].detach().cpu(), b.detach()), (variant, k)
+        k_pts = int(mask[:-1].sum())
+        assert sur_h["position"].shape[0] == k_pts and sur_h["geo_feature"].shape[0] == int(mask.sum())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("voxel,n,extent", [(0.3, 200_000, 60.0), (0.1, 400_000, 25.0)])
 def test_map_hip_matches_oracle_large_random(voxel, n, extent):
@@ -251,6 +332,7 @@ def test_map_hip_matches_oracle_large_random(voxel, n, extent):
                   "local_point_certainties", "local_point_ts_update", "local_point_colors", "local_valid_color_mask",
                   "local_valid_gs_mask", "local_free_gs_mask", "local_geo_features", "local_color_features"):
             assert torch.equal(getattr(mh, k).detach().cpu(), getattr(mc, k)), (ts, k)
+        _check_gather_local_data(mc, mh, ts)
         for m_ in (mc, mh):
             with torch.no_grad():
                 m_.local_geo_features += 0.25
