@@ -319,8 +319,9 @@ def gather_local_data(m, with_sorroundings: bool = True):
     `nonzero` + host synchronisation per indexed tensor (nine); here the mask becomes a row list once (one polled
     read-back) and all tensors are gathered by one launch."""
     data = {
-        "position": m.local_neural_points, "orientation": m.local_point_orientations, "color": m.local_point_colors,
-        "geo_feature": m.local_geo_features, "color_feature": m.local_color_features, "resolution": m.resolution,
+        "position": m.local_neural_points, "orientation": m.local_point_orientations,
+        "color": getattr(m, "local_point_colors", None), "geo_feature": m.local_geo_features,
+        "color_feature": getattr(m, "local_color_features", None), "resolution": m.resolution,
         "free_mask": m.local_free_gs_mask, "valid_mask": m.local_valid_gs_mask, "stability": m.local_point_certainties,
     }
     if not with_sorroundings:
