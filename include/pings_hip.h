@@ -260,6 +260,12 @@ PINGS_API int pings_knn_blocks_build(const pings_knn_map* m, int64_t num_points,
 PINGS_API int pings_knn_search(const pings_knn_map* m, const float* queries, int64_t B,
                                int64_t* idx, float* d2, int64_t* nn_counts, int64_t* global_idx,
                                void* stream);
+/* `NeuralPoints.radius_neighborhood_search` itself (model/neural_gaussians.py:1061-1115): d2[B,K] (float) and idx[B,K]
+ * (int64, -1 = no point) for every candidate cell, with the reference's step order (time window, python index -1 =
+ * the last point, max_valid_dist2 for empty entries, collisions keep their distance).  num_points = rows of
+ * neural_points.  The fused entry points never form this pair; `query_certainty` (:1117-1133) consumes it. */
+PINGS_API int pings_knn_cells(const pings_knn_map* m, const float* queries, int64_t B, int64_t num_points, float* d2,
+                              int64_t* idx, void* stream);
 
 /* ---- NeuralPoints.query_feature (model/neural_gaussians.py:506-725): forward, backward, double backward ----
  * The tables are the LOCAL ones for a local query (local_geo_features [N_local+1, Fg], local_color_features,

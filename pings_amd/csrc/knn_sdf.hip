@@ -407,6 +407,59 @@ PINGS_API int pings_knn_search(const pings_knn_map* m, const float* queries, int
   return PINGS_OK;
 }
 
+namespace {
+// `radius_neighborhood_search` as it stands (model/neural_gaussians.py:1061-1115): one thread per (query, cell).  The
+// fused search above never forms this [B, K] pair; callers that want it (query_certainty, :1117-1133) get it here.
+// Order of the reference's steps kept: the time window drops an entry first, an empty / dropped entry reads the LAST
+// point (python's index -1) and gets max_valid_dist2, then a distance above the bound (a hash collision) clears the
+// index but keeps its distance.
+__global__ __launch_bounds__(256) void knn_cells_kernel(pings_knn_map m, const float* __restrict__ q, long long B,
+                                                         long long num_points, float* __restrict__ d2,
+                                                         long long* __restrict__ idx) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * m.K) return;
+  const long long b = e / m.K;
+  const int k = (int)(e - b * m.K);
+  const float qx = q[3 * b], qy = q[3 * b + 1], qz = q[3 * b + 2];
+  const long long gx = (long long)floorf(qx / m.resolution) + m.neighbor_dx[3 * k];
+  const long long gy = (long long)floorf(qy / m.resolution) + m.neighbor_dx[3 * k + 1];
+  const long long gz = (long long)floorf(qz / m.resolution) + m.neighbor_dx[3 * k + 2];
+  const long long h = hash_slot(gx * P0 + gy * P1 + gz * P2, m.buffer_size, 1.0 / (double)m.buffer_size);
+  long long i = table_lookup(m, h);
+  const long long last = num_points - 1;                 // what index -1 reads
+  if (m.time_filtering) {
+    const int ts = m.point_ts_create[i >= 0 ? i : last];
+    if (!(fabsf(m.travel_dist[m.cur_ts] - m.travel_dist[ts]) < m.diff_travel_dist_local)) i = -1;
+  }
+  const long long r = i >= 0 ? i : last;
+  const float sx = m.neural_points[3 * r] - qx, sy = m.neural_points[3 * r + 1] - qy, sz = m.neural_points[3 * r + 2] - qz;
+  float dd = (sx * sx + sy * sy) + sz * sz;
+  if (i < 0) dd = m.max_valid_dist2;
+  if (dd > m.max_valid_dist2) i = -1;
+  d2[e] = dd;
+  idx[e] = i;
+}
+}  // namespace
+
+PINGS_API int pings_knn_cells(const pings_knn_map* m, const float* queries, int64_t B, int64_t num_points, float* d2,
+                              int64_t* idx, void* stream) {
+  // the raw pair has no nn_k: any K (the mapper calls it with the one-cell neighbourhood, K = 1 < nn_k)
+  PINGS_ARG_CHECK(m != nullptr, "null map");
+  PINGS_ARG_CHECK((m->table || m->compact) && m->buffer_size > 0 && m->buffer_size < (1LL << 31) && m->neural_points &&
+                      m->neighbor_dx && m->K > 0 && m->resolution > 0.f,
+                  "bad map");
+  PINGS_ARG_CHECK(!m->compact || ((m->compact_mask & (m->compact_mask + 1u)) == 0u), "compact_mask must be 2^k - 1");
+  PINGS_ARG_CHECK(!m->time_filtering || (m->point_ts_create && m->travel_dist), "time filtering needs ts / travel_dist");
+  if (B == 0) return PINGS_OK;
+  PINGS_ARG_CHECK(B > 0 && num_points > 0 && queries && d2 && idx, "bad arguments");
+  hipStream_t st = pings::as_stream(stream);
+  const long long total = (long long)B * m->K;
+  hipLaunchKernelGGL(knn_cells_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *m, queries,
+                     (long long)B, (long long)num_points, d2, (long long*)idx);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
 PINGS_API int pings_sdf_forward(const pings_knn_map* m, const pings_sdf_decoder* dec,
                                 const float* features, const float* points,
                                 const float* orientations, const float* certainties,

@@ -77,6 +77,8 @@ def _declare(L):
     L.pings_rows_scatter_add_scratch_bytes.argtypes = [C.c_int64, C.c_int64]
     L.pings_rows_scatter_add.restype = C.c_int
     L.pings_rows_scatter_add.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, vp, C.c_int64, vp, vp, vp]
+    L.pings_knn_cells.restype = C.c_int
+    L.pings_knn_cells.argtypes = [C.POINTER(_CKnnMap), vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.pings_knn_search.restype = C.c_int
     L.pings_knn_search.argtypes = [C.POINTER(_CKnnMap), vp, C.c_int64, vp, vp, vp, vp, vp]
     L.pings_knn_compact_entries.restype = C.c_size_t
@@ -229,7 +231,8 @@ def _as_u8(mask: torch.Tensor) -> torch.Tensor:
 class _MapArgs:
     """Builds the C struct and keeps every tensor it points to alive."""
 
-    def __init__(self, npm, time_filtering: bool, use_free: bool, use_valid: bool, query_locally: bool):
+    def __init__(self, npm, time_filtering: bool, use_free: bool, use_valid: bool, query_locally: bool,
+                 index: bool = True):
         dev = npm.neural_points.device
         if not npm.neural_points.is_cuda:
             raise _lib.PingsHipError("the neural-point map must live on the HIP device (no CPU fallback)")
@@ -249,13 +252,13 @@ class _MapArgs:
         g2l = npm.global2local.contiguous() if query_locally else None
         dx = _dx32(npm)
         blk = None
-        if KNN_INDEX == "blocks" and table.shape[0] < (1 << 31):
+        if index and KNN_INDEX == "blocks" and table.shape[0] < (1 << 31):
             blk = _block_index(npm)
             b = blk.baked
             if (time_filtering and not b["ts"]) or (use_free and not b["free"]) or (use_valid and not b["valid"]) or \
                     (query_locally and not b["g2l"]):
                 blk = None
-        comp = _compact_table(npm) if (USE_COMPACT_TABLE and blk is None) else None
+        comp = _compact_table(npm) if (index and USE_COMPACT_TABLE and blk is None) else None
         self.c = _CKnnMap(
             k(table.contiguous()), int(table.shape[0]), k(npm.neural_points.contiguous()),
             k(ts.contiguous()) if ts is not None else None, k(td) if td is not None else None,
@@ -307,6 +310,24 @@ def radius_neighborhood_topk(npm, points: torch.Tensor, time_filtering: bool = F
     if return_global:
         return idx, d2, cnt, gidx
     return idx, d2, cnt
+
+
+def radius_neighborhood_search(self, points: torch.Tensor, time_filtering: bool = False):
+    """`NeuralPoints.radius_neighborhood_search` (model/neural_gaussians.py:1061-1115) as it stands: (dist2[B,K] fp32,
+    idx[B,K] int64, -1 = no point) for every candidate cell.  The query paths use the fused search
+    (`radius_neighborhood_topk`); this is for the callers that want the raw pair — `query_certainty` (:1117-1133), which
+    the mapper runs on every frame's new samples with the one-cell neighbourhood (utils/mapper.py:461-475).  Reads the
+    reference's table directly (no search index is built for it: the neighbourhood changes around the call)."""
+    L = _L()
+    pts = points.detach().to(torch.float32).contiguous()
+    B = int(pts.shape[0])
+    a = _MapArgs(self, time_filtering, False, False, False, index=False)
+    K = int(a.c.K)
+    d2 = torch.empty(B, K, dtype=torch.float32, device=pts.device)
+    idx = torch.empty(B, K, dtype=torch.int64, device=pts.device)
+    _lib.check(L.pings_knn_cells(C.byref(a.c), _lib.ptr(pts), B, int(self.neural_points.shape[0]), _lib.ptr(d2),
+                                 _lib.ptr(idx), _lib.stream_ptr(pts.device)), "pings_knn_cells")
+    return d2, idx
 
 
 def rows_scatter_add(dst_row: torch.Tensor, src: torch.Tensor, rows: int, w: torch.Tensor = None,
@@ -1086,3 +1107,4 @@ def numerical_gradient(npm, decoder, x, sdf_x=None, eps=0.02, two_side=True):
 def install(neural_points_cls) -> None:
     """Route the reference's `NeuralPoints.query_feature` through the HIP search kernel."""
     neural_points_cls.query_feature = query_feature
+    neural_points_cls.radius_neighborhood_search = radius_neighborhood_search

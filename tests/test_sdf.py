@@ -121,6 +121,40 @@ def test_hip_topk_is_index_exact(golden_dir, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
+def test_hip_radius_search_matches_reference_golden(golden_dir, name):
+    """`radius_neighborhood_search` as it stands (model/neural_gaussians.py:1061-1115) against the reference's own
+    outputs (G1): every candidate cell's index and squared distance bit for bit, with and without the travel-distance
+    window; then `query_certainty` (:1117-1133) on top of it with the mapper's one-cell neighbourhood
+    (utils/mapper.py:461-475) against the oracle."""
+    from pings_amd import neural_points as hnp
+
+    st = load(golden_dir, name)
+    gpu = _gpu_map(st)
+    x = T(st["x"])
+    for tf in (0, 1):
+        d2, idx = hnp.radius_neighborhood_search(gpu, x.cuda(), time_filtering=bool(tf))
+        assert torch.equal(idx.cpu(), T(st[f"g1_idx_tf{tf}"]))
+        assert torch.equal(d2.cpu(), T(st[f"g1_d2_tf{tf}"]))
+    cpu = sdf_cpu.NeuralPointMap(st)
+    one_cell = sdf_cpu.neighbor_offsets(1, 0.0)
+    assert one_cell.shape[0] == 1
+    for m_ in (cpu, gpu):
+        m_.neighbor_dx = one_cell.to(m_.neural_points.device)
+        m_.max_valid_dist2 = 3 * ((1 + 1) * m_.resolution) ** 2
+
+    def certainty(m_, search, pts):   # the reference's query_certainty, line by line
+        _, i = search(pts)
+        c = m_.point_certainties[i]
+        c[i < 0] = 0.0
+        return torch.max(c, dim=-1)[0]
+
+    ref = certainty(cpu, cpu.radius_neighborhood_search, x)
+    got = certainty(gpu, lambda p: hnp.radius_neighborhood_search(gpu, p), x.cuda())
+    assert torch.equal(got.cpu(), ref) and float(ref.max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
 def test_hip_query_feature_matches_reference_golden(golden_dir, name):
     from pings_amd import neural_points as hnp
 
