@@ -262,7 +262,7 @@ def bin_and_sort(geom, s: Settings):
 
 
 def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=None, rho=None,
-              return_debug=False, margins=False):
+              return_debug=False, margins=False, tile_subset=None):
     """Forward pass.  All tensor inputs share one dtype (float32 or float64).
     surfel -> dict(color[3,H,W], normal[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P], contributions[P])
     3dgs   -> dict(color, depth (un-normalised), alpha, radii, n_touched[P])"""
@@ -313,6 +313,12 @@ def rasterize(means3D, colors, opacities, scales, rotations, s: Settings, theta=
             t = ty * gx + tx
             y0, x0 = ty * TILE, tx * TILE
             y1, x1 = min(y0 + TILE, H), min(x0 + TILE, W)
+            if tile_subset is not None and not tile_subset(tx, ty):
+                # (tests of full-size scenes blend a checkerboard of tiles: pixels of the others stay zero)
+                n0 = (y1 - y0) * (x1 - x0)
+                color_parts.append((y0, y1, x0, x1, torch.zeros(3, n0, dtype=dt), torch.zeros(3, n0, dtype=dt),
+                                    torch.zeros(n0, dtype=dt), torch.zeros(n0, dtype=dt)))
+                continue
             iy, ix = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
             npix = iy.numel()
             pixx = ix.reshape(-1).to(dt)
