@@ -1,4 +1,4 @@
-"""The five spawn decoders alone (bench.py's decoder leg): python tools/dec_bench.py   [PINGS_MLP_BWD_1W=1 for the A/B]"""
+"""The five spawn decoders alone (bench.py decoder leg): python tools/dec_bench.py"""
 import json
 import os
 import sys
