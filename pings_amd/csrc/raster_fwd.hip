@@ -2307,6 +2307,9 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   // long lists in parallel segments (see blend_fwd_seg_kernel): PINGS_BLEND_SEG = entries per segment, 0 = off
   const uint32_t seg = blend_segment_entries();
   const bool seg_on = seg > 0 && I > (int64_t)num_tiles * (seg / 4) && I > 2 * (int64_t)seg;
+  // side stream of the segment passes (raster_common.hpp; PINGS_SIDE_STREAM=0: everything on `st`)
+  static thread_local SideStream side;
+  const bool side_ok = seg_on && side.usable();
 #define PINGS_BLEND_FWD_WAVE(M)                                                                        \
   do {                                                                                                 \
     if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_wq, 0, 16 * (size_t)I, st));                     \
@@ -2316,22 +2319,31 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                          bs.seg_max_units, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_tile_unit0); \
       PINGS_LAUNCH_CHECK();                                                                            \
     }                                                                                                  \
+    /* the segmented tiles and the short-list tiles are disjoint: the three segment passes run on a side stream   \
+       next to the short-list kernel (both sit in s_waitcnt a third of the time) and join before the per-instance  \
+       sums are folded */                                                                              \
+    hipStream_t sseg = st;                                                                             \
+    if (side_ok) {                                                                                     \
+      sseg = side.stream;                                                                              \
+      PINGS_ARG_CHECK(side.begin(st) == 0, "side stream fork failed");                                 \
+    }                                                                                                  \
     hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(4 * num_tiles), dim3(64), 0, st, kp, bs.ranges, \
                        bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
                        im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order,              \
                        seg_on ? bs.seg_tile_unit0 : nullptr);                                          \
     if (seg_on) {                                                                                      \
       const dim3 gseg(4u * bs.seg_max_units);                                                          \
-      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 0>), gseg, dim3(64), 0, st, kp, bs.ranges, bs.point_list, gs.rec, \
+      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 0>), gseg, dim3(64), 0, sseg, kp, bs.ranges, bs.point_list, gs.rec, \
                          bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
                          bs.inst_wq, bs.inst_cntq);                                                    \
-      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 1>), gseg, dim3(64), 0, st, kp, bs.ranges, bs.point_list, gs.rec, \
+      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 1>), gseg, dim3(64), 0, sseg, kp, bs.ranges, bs.point_list, gs.rec, \
                          bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
                          bs.inst_wq, bs.inst_cntq);                                                    \
-      hipLaunchKernelGGL((blend_fwd_seg_combine_kernel<M>), gseg, dim3(64), 0, st, kp, bs.ranges, seg, bs.seg_head, \
+      hipLaunchKernelGGL((blend_fwd_seg_combine_kernel<M>), gseg, dim3(64), 0, sseg, kp, bs.ranges, seg, bs.seg_head, \
                          bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_slab, out_color, out_normal, out_depth, \
                          out_alpha, im.final_T, im.n_contrib);                                         \
       PINGS_LAUNCH_CHECK();                                                                            \
+      if (sseg != st) PINGS_ARG_CHECK(side.end(st) == 0, "side stream join failed");                   \
     }                                                                                                  \
     if (I > 0)                                                                                         \
       hipLaunchKernelGGL((combine_quadrants_kernel<M>), dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), \
