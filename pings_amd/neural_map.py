@@ -248,20 +248,18 @@ def reset_local_map(m, sensor_position, sensor_orientation=None, cur_ts: int = 0
     m.local_mask = local_mask
     m.global2local = g2l
     m._local_idx = lidx[:nl + 1]
-    rows = lidx[:nl]
-    m.local_neural_points = _gather(L, m.neural_points, rows, nl)
-    m.local_point_orientations = _gather(L, m.point_orientations, rows, nl)
-    m.local_point_certainties = _gather(L, m.point_certainties, rows, nl)
-    m.local_point_ts_update = _gather(L, m.point_ts_update, rows, nl)
+    # every local tensor in ONE gather launch (ten before); the features carry the padding row (:471-475): lidx[nl] = n
+    names = [("local_neural_points", m.neural_points, nl), ("local_point_orientations", m.point_orientations, nl),
+             ("local_point_certainties", m.point_certainties, nl), ("local_point_ts_update", m.point_ts_update, nl),
+             ("local_valid_color_mask", m.valid_color_mask, nl), ("local_valid_gs_mask", m.valid_gs_mask, nl),
+             ("local_free_gs_mask", m.free_gs_mask, nl), ("local_geo_features", m.geo_features, nl + 1)]
     if getattr(m, "point_colors", None) is not None:
-        m.local_point_colors = _gather(L, m.point_colors, rows, nl)
-    m.local_valid_color_mask = _gather(L, m.valid_color_mask, rows, nl)
-    m.local_valid_gs_mask = _gather(L, m.valid_gs_mask, rows, nl)
-    m.local_free_gs_mask = _gather(L, m.free_gs_mask, rows, nl)
-    geo = _gather(L, m.geo_features, lidx[:nl + 1], nl + 1)            # features carry the padding row (:471-475)
-    m.local_geo_features = torch.nn.Parameter(geo)
+        names.append(("local_point_colors", m.point_colors, nl))
     if getattr(m, "color_features", None) is not None:
-        m.local_color_features = torch.nn.Parameter(_gather(L, m.color_features, lidx[:nl + 1], nl + 1))
+        names.append(("local_color_features", m.color_features, nl + 1))
+    outs = _gather_many(L, [(t, k) for _, t, k in names], lidx)
+    for (name, _, _), o in zip(names, outs):
+        setattr(m, name, torch.nn.Parameter(o) if name in ("local_geo_features", "local_color_features") else o)
     m.local_orientation = sensor_orientation
     m.local_position = sensor.float()
 
