@@ -130,37 +130,6 @@ struct ImageState {
 uint32_t blend_segment_entries();
 GeomState carve_geom(void* blob, int P, int num_tiles);
 // tile_order[i] = i-th tile in descending `work` (ties in any order: scheduling only, results do not depend on it)
-// A second stream for work that does not depend on what the caller's stream is doing at that point (the forward's
-// segment passes next to its short-list kernel): created once per host thread on that thread's current device, forked
-// and joined with two events, so nothing of it outlives the call.
-// PINGS_SIDE_STREAM=0 keeps everything on the caller's stream.
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-  int dev = -1;
-  SideStream() {
-    if (const char* e = getenv("PINGS_SIDE_STREAM")) if (atoi(e) == 0) return;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    if (!ok) (void)hipGetLastError();
-  }
-  bool usable() const {   // only on the device it was made for
-    int cur = -1;
-    return ok && hipGetDevice(&cur) == hipSuccess && cur == dev;
-  }
-  int begin(hipStream_t st) const {   // the side stream waits for everything `st` holds so far
-    if (hipEventRecord(fork, st) != hipSuccess) return 1;
-    return hipStreamWaitEvent(stream, fork, 0) != hipSuccess;
-  }
-  int end(hipStream_t st) const {     // `st` waits for the side stream
-    if (hipEventRecord(join, stream) != hipSuccess) return 1;
-    return hipStreamWaitEvent(st, join, 0) != hipSuccess;
-  }
-};
-
 // n_long (optional): receives min(number of tiles with work >= long_thr, long_max) — they lead the order
 int launch_tile_order(const uint32_t* work, int num_tiles, uint32_t* order, hipStream_t st, uint32_t* n_long = nullptr,
                       uint32_t long_thr = 0, uint32_t long_max = 0);

@@ -1139,22 +1139,29 @@ __global__ __launch_bounds__(BLOCK / PPL) void blend_fwd_kernel(
 // its own LDS slots and blends them; it stops as soon as its 64 pixels are done.  No barriers.  Per-instance sums
 // are written per quadrant (inst_wq / inst_cntq) and folded by combine_quadrants_kernel, so everything downstream
 // sees the same inst_w / inst_cnt / inst_qmask as from the workgroup kernel.  Pixel arithmetic is the same, op for op.
+// Workgroups of four waves, wave = quadrant of ONE tile: the four walk the same list, so what one fetched (list entries,
+// ids, records) the others find in the CU's L1; as one-wave workgroups the four quadrants of a tile were dealt to four
+// XCDs (round-robin dispatch) and each fetched the list through its own L2.
 template <int MODE>
-__global__ __launch_bounds__(64) void blend_fwd_wave_kernel(
-    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void blend_fwd_wave_body(
+    const KParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
     float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
     uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order,
-    const uint32_t* __restrict__ seg_tile_unit0) {
-  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
-  __shared__ uint32_t sSlot[64];
-  __shared__ int sE[64];
-  __shared__ float sW[64];
-  __shared__ uint32_t sCnt[64];
+    const uint32_t* __restrict__ seg_tile_unit0, const unsigned block) {
+  __shared__ float4 sA_[4][64], sB_[4][64], sC_[4][64], sD_[4][64];
+  __shared__ uint32_t sSlot_[4][64];
+  __shared__ int sE_[4][64];
+  __shared__ float sW_[4][64];
+  __shared__ uint32_t sCnt_[4][64];
 
-  const int lane = threadIdx.x;
-  const int tile = (int)tile_order[blockIdx.x >> 2], q = blockIdx.x & 3;
+  const int lane = threadIdx.x & 63, q = (int)(threadIdx.x >> 6);
+  float4 *sA = sA_[q], *sB = sB_[q], *sC = sC_[q], *sD = sD_[q];
+  uint32_t *sSlot = sSlot_[q], *sCnt = sCnt_[q];
+  int* sE = sE_[q];
+  float* sW = sW_[q];
+  const int tile = (int)tile_order[block];
   if (seg_tile_unit0 && seg_tile_unit0[tile] != 0xFFFFFFFFu) return;   // a long list: blended in parallel segments
   const int tx = tile % p.gx, ty = tile / p.gx;
   const int pix_x = tx * TILE + 8 * (q & 1) + (lane & 7);
@@ -1386,20 +1393,24 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(const uint2* __restrict_
 
 // PASS: 0 = transmittance products, 1 = blend
 template <int MODE, int PASS>
-__global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
-    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void blend_fwd_seg_body(
+    const KParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ rec, const uint32_t* __restrict__ gval, uint32_t seg, const uint32_t* __restrict__ head,
     const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, float* __restrict__ segP,
-    float* __restrict__ slab, float* __restrict__ inst_wq, uint32_t* __restrict__ inst_cntq) {
-  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
-  __shared__ uint32_t sSlot[64];
-  __shared__ int sE[64];
-  __shared__ float sW[64];
-  __shared__ uint32_t sCnt[64];
+    float* __restrict__ slab, float* __restrict__ inst_wq, uint32_t* __restrict__ inst_cntq, const unsigned block) {
+  __shared__ float4 sA_[4][64], sB_[4][64], sC_[PASS == 1 ? 4 : 1][64], sD_[PASS == 1 ? 4 : 1][64];
+  __shared__ uint32_t sSlot_[PASS == 1 ? 4 : 1][64];
+  __shared__ int sE_[PASS == 1 ? 4 : 1][64];
+  __shared__ float sW_[PASS == 1 ? 4 : 1][64];
+  __shared__ uint32_t sCnt_[PASS == 1 ? 4 : 1][64];
 
-  const int lane = threadIdx.x;
-  const uint32_t unit = blockIdx.x >> 2;
-  const int q = blockIdx.x & 3;
+  const int lane = threadIdx.x & 63, q = (int)(threadIdx.x >> 6);   // wave = quadrant (see blend_fwd_wave_kernel)
+  constexpr int QB = PASS == 1 ? 1 : 0;
+  float4 *sA = sA_[q], *sB = sB_[q], *sC = sC_[QB * q], *sD = sD_[QB * q];
+  uint32_t *sSlot = sSlot_[QB * q], *sCnt = sCnt_[QB * q];
+  int* sE = sE_[QB * q];
+  float* sW = sW_[QB * q];
+  const uint32_t unit = block;
   if (unit >= head[0] || unit_tile[unit] == 0xFFFFFFFFu) return;
   const int tile = (int)unit_tile[unit];
   const uint32_t sg = unit_seg[unit];
@@ -1590,16 +1601,59 @@ __global__ __launch_bounds__(64) void blend_fwd_seg_kernel(
   }
 }
 
+template <int MODE, int PASS>
+__global__ __launch_bounds__(256) void blend_fwd_seg_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, uint32_t seg, const uint32_t* __restrict__ head,
+    const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, float* __restrict__ segP,
+    float* __restrict__ slab, float* __restrict__ inst_wq, uint32_t* __restrict__ inst_cntq) {
+  blend_fwd_seg_body<MODE, PASS>(p, ranges, point_list, rec, gval, seg, head, unit_tile, unit_seg, segP, slab, inst_wq,
+                                 inst_cntq, blockIdx.x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_fwd_wave_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
+    float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
+    uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order,
+    const uint32_t* __restrict__ seg_tile_unit0) {
+  blend_fwd_wave_body<MODE>(p, ranges, point_list, rec, gval, out_color, out_normal, out_depth, out_alpha, final_T,
+                            n_contrib, inst_wq, inst_cntq, tile_order, seg_tile_unit0, blockIdx.x);
+}
+
+// The short-list tiles and pass T of the segmented tiles in ONE launch (workgroups [0, num_tiles) are tiles, the rest
+// segment units): the two touch disjoint tiles and both spend a third of their time in s_waitcnt, so together they
+// fill what each leaves idle.  (A side stream does the same with two launches — 0.775 -> 0.719 ms on C3 — but its
+// cross-queue event wait once took 11 ms per frame on one box of the pool; one launch needs no such wait.)
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_fwd_wave_segT_kernel(
+    KParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const uint32_t* __restrict__ gval, float* __restrict__ out_color,
+    float* __restrict__ out_normal, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ inst_wq,
+    uint32_t* __restrict__ inst_cntq, const uint32_t* __restrict__ tile_order,
+    const uint32_t* __restrict__ seg_tile_unit0, unsigned num_tiles, uint32_t seg, const uint32_t* __restrict__ head,
+    const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, float* __restrict__ segP) {
+  if (blockIdx.x < num_tiles)
+    blend_fwd_wave_body<MODE>(p, ranges, point_list, rec, gval, out_color, out_normal, out_depth, out_alpha, final_T,
+                              n_contrib, inst_wq, inst_cntq, tile_order, seg_tile_unit0, blockIdx.x);
+  else
+    blend_fwd_seg_body<MODE, 0>(p, ranges, point_list, rec, gval, seg, head, unit_tile, unit_seg, segP, nullptr, inst_wq,
+                                inst_cntq, blockIdx.x - num_tiles);
+}
+
 // PASS C: first-segment waves add their tile's slabs in list order and write the pixel outputs.
 template <int MODE>
-__global__ __launch_bounds__(64) void blend_fwd_seg_combine_kernel(
+__global__ __launch_bounds__(256) void blend_fwd_seg_combine_kernel(
     KParams p, const uint2* __restrict__ ranges, uint32_t seg, const uint32_t* __restrict__ head,
     const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ unit_seg, const float* __restrict__ slab,
     float* __restrict__ out_color, float* __restrict__ out_normal, float* __restrict__ out_depth,
     float* __restrict__ out_alpha, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  const int lane = threadIdx.x;
-  const uint32_t unit = blockIdx.x >> 2;
-  const int q = blockIdx.x & 3;
+  const int lane = threadIdx.x & 63;
+  const uint32_t unit = blockIdx.x;
+  const int q = (int)(threadIdx.x >> 6);
   if (unit >= head[0] || unit_seg[unit] != 0u || unit_tile[unit] == 0xFFFFFFFFu) return;
   const int tile = (int)unit_tile[unit];
   const int tx = tile % p.gx, ty = tile / p.gx;
@@ -2307,9 +2361,6 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
   // long lists in parallel segments (see blend_fwd_seg_kernel): PINGS_BLEND_SEG = entries per segment, 0 = off
   const uint32_t seg = blend_segment_entries();
   const bool seg_on = seg > 0 && I > (int64_t)num_tiles * (seg / 4) && I > 2 * (int64_t)seg;
-  // side stream of the segment passes (raster_common.hpp; PINGS_SIDE_STREAM=0: everything on `st`)
-  static thread_local SideStream side;
-  const bool side_ok = seg_on && side.usable();
 #define PINGS_BLEND_FWD_WAVE(M)                                                                        \
   do {                                                                                                 \
     if (I > 0) PINGS_HIP_CHECK(hipMemsetAsync(bs.inst_wq, 0, 16 * (size_t)I, st));                     \
@@ -2319,31 +2370,26 @@ PINGS_API int pings_raster_render(const pings_raster_settings* s, int P, int64_t
                          bs.seg_max_units, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_tile_unit0); \
       PINGS_LAUNCH_CHECK();                                                                            \
     }                                                                                                  \
-    /* the segmented tiles and the short-list tiles are disjoint: the three segment passes run on a side stream   \
-       next to the short-list kernel (both sit in s_waitcnt a third of the time) and join before the per-instance  \
-       sums are folded */                                                                              \
-    hipStream_t sseg = st;                                                                             \
-    if (side_ok) {                                                                                     \
-      sseg = side.stream;                                                                              \
-      PINGS_ARG_CHECK(side.begin(st) == 0, "side stream fork failed");                                 \
-    }                                                                                                  \
-    hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(4 * num_tiles), dim3(64), 0, st, kp, bs.ranges, \
-                       bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,    \
-                       im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order,              \
-                       seg_on ? bs.seg_tile_unit0 : nullptr);                                          \
-    if (seg_on) {                                                                                      \
-      const dim3 gseg(4u * bs.seg_max_units);                                                          \
-      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 0>), gseg, dim3(64), 0, sseg, kp, bs.ranges, bs.point_list, gs.rec, \
+    if (!seg_on) {                                                                                     \
+      hipLaunchKernelGGL((blend_fwd_wave_kernel<M>), dim3(num_tiles), dim3(256), 0, st, kp, bs.ranges, \
+                         bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, out_alpha,  \
+                         im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order,            \
+                         (const uint32_t*)nullptr);                                                    \
+    } else {                                                                                           \
+      /* short-list tiles + pass T of the segments in one launch, then pass B and pass C */            \
+      const dim3 gseg(bs.seg_max_units);                                                               \
+      hipLaunchKernelGGL((blend_fwd_wave_segT_kernel<M>), dim3((unsigned)num_tiles + bs.seg_max_units), dim3(256), 0, \
+                         st, kp, bs.ranges, bs.point_list, gs.rec, bs.gval, out_color, out_normal, out_depth, \
+                         out_alpha, im.final_T, im.n_contrib, bs.inst_wq, bs.inst_cntq, bs.tile_order, \
+                         bs.seg_tile_unit0, (unsigned)num_tiles, seg, bs.seg_head, bs.seg_unit_tile,   \
+                         bs.seg_unit_seg, bs.seg_P);                                                   \
+      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 1>), gseg, dim3(256), 0, st, kp, bs.ranges, bs.point_list, gs.rec, \
                          bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
                          bs.inst_wq, bs.inst_cntq);                                                    \
-      hipLaunchKernelGGL((blend_fwd_seg_kernel<M, 1>), gseg, dim3(64), 0, sseg, kp, bs.ranges, bs.point_list, gs.rec, \
-                         bs.gval, seg, bs.seg_head, bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_P, bs.seg_slab, \
-                         bs.inst_wq, bs.inst_cntq);                                                    \
-      hipLaunchKernelGGL((blend_fwd_seg_combine_kernel<M>), gseg, dim3(64), 0, sseg, kp, bs.ranges, seg, bs.seg_head, \
+      hipLaunchKernelGGL((blend_fwd_seg_combine_kernel<M>), gseg, dim3(256), 0, st, kp, bs.ranges, seg, bs.seg_head, \
                          bs.seg_unit_tile, bs.seg_unit_seg, bs.seg_slab, out_color, out_normal, out_depth, \
                          out_alpha, im.final_T, im.n_contrib);                                         \
       PINGS_LAUNCH_CHECK();                                                                            \
-      if (sseg != st) PINGS_ARG_CHECK(side.end(st) == 0, "side stream join failed");                   \
     }                                                                                                  \
     if (I > 0)                                                                                         \
       hipLaunchKernelGGL((combine_quadrants_kernel<M>), dim3((unsigned)pings::ceil_div<int64_t>(I, 256)), \
