@@ -143,6 +143,12 @@ def best_threads(fn, candidates=(8, 16, 32, 64, 128)):
     return torch.get_num_threads()
 
 
+# largest fraction of (pixels, Gaussians) the parity gates may set aside as "undecidable in fp32" per test scene
+# (measured in round 4: street 0.034 % / 21.6 %, room 0.036 % / 5.5 %, cloud 27.8 % / 21.0 % — the pixel
+# ceilings are the verdict's, the Gaussian ceilings twice the measured values)
+UNDECIDABLE_CEILING = {"street": (0.001, 0.45), "room": (0.001, 0.12), "cloud": (0.30, 0.45)}
+
+
 def cpu_baseline_raster(dev, P_sample=16000, W=480, H=272):
     """The oracle (kind "port") timed on a bounded sample of the raster workload — the same cloud statistics,
     P_sample Gaussians, WxH pixels, fp32, fwd + autograd bwd, on the host cores — and, since the oracle's outputs
@@ -215,8 +221,23 @@ def cpu_baseline_raster(dev, P_sample=16000, W=480, H=272):
         d = d.amax(0) if per_pixel else d.reshape(d.shape[0], -1).amax(1)
         return float(f"{d[~flag].max().item() / scale:.3e}")
 
+    def rel_l2_flagged(a, b, flag):
+        """relative L2 error over the FLAGGED pixels alone (they are not exempt: bounded at 1e-3)"""
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        if not bool(flag.any()):
+            return 0.0
+        return float(f"{((a - b)[:, flag].norm() / max(b[:, flag].norm().item(), 1e-30)).item():.3e}")
+
+    # VERDICT r3 #5: the undecidable set must not grow silently.  Ceilings for THIS scene (the cloud's thin footprints
+    # put a rounding bound above 2e-5 on ~28 % of the pixels; tests/test_raster.py holds the street / room ceilings)
+    pix_frac, g_frac = float(pix_flag.float().mean()), float(g_flag.float().mean())
     parity = {"format": "[max_rel_err, rel_l2_err, entries > 1e-4, max_rel_err over the DECIDABLE pixels / Gaussians]",
               "undecidable_pixels": int(pix_flag.sum()), "undecidable_gaussians": int(g_flag.sum()),
+              "undecidable_pixel_frac": round(pix_frac, 5), "undecidable_gaussian_frac": round(g_frac, 5),
+              "undecidable_frac_ceiling": {"pixels": UNDECIDABLE_CEILING["cloud"][0], "gaussians": UNDECIDABLE_CEILING["cloud"][1]},
+              "undecidable_within_ceiling": bool(pix_frac <= UNDECIDABLE_CEILING["cloud"][0]
+                                                 and g_frac <= UNDECIDABLE_CEILING["cloud"][1]),
+              "flagged_pixels_rel_l2": {k: rel_l2_flagged(t, out[k], pix_flag) for k, t in zip(keys, (img, nrm, dep, alp))},
               "radii_equal": bool((radii.cpu() == out["radii"]).all())}
     for k, t in zip(keys, (img, nrm, dep, alp)):
         parity[k] = rel(t, out[k]) + [rel_outside(t, out[k], pix_flag, True)]
@@ -867,12 +888,20 @@ class _BenchDecoder(torch.nn.Module):
         self.to(device)
 
 
-def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8):
+def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8, exchange=None):
     """One iteration of the Gaussian-mapping loop body as an unmodified mapper reaches it (utils/mapper.py:1126-1295,
     :1581): `render()` (markVisible -> spawn + the five decoders -> rasterise -> depth2normal -> exposure), the
     photometric loss block, fused-SSIM, backward to the neural-point features, the decoders, exposure and pose.
     The rasteriser object is constructed inside render() on every call, as the reference does (:149-201).
-    n_points neural points on a street-like surface, K Gaussians each (F_g 32, F_c 16, hidden 128, pings.py:156-160)."""
+    n_points neural points on a street-like surface, K Gaussians each (F_g 32, F_c 16, hidden 128, pings.py:156-160).
+
+    exchange = (world, rank) with world > 1: the multi-view step of SURVEY 8e as a training script would run it
+     — every rank renders ITS camera of the rig (yawed by rank) over the same local map; the five
+    decoders' parameters live in a hooked `GradBucket` (`zero(1)`; the all-reduce is fired from the post-accumulate
+    hook of the last decoder gradient, i.e. from inside `loss.backward()`, while the spawn gather adjoint and the
+    feature scatter still run), and the feature-table gradients — the ACTUAL spawn / decoder adjoint — travel through
+    `RowSparseExchange` with the rows this view touched.  Called by every rank; the returned time is the max."""
+    import math as _m
     from pings_amd import _lib
     from pings_amd.camera import Camera
     from pings_amd.image_losses import image_losses
@@ -896,34 +925,76 @@ def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8)
             "resolution": 0.2, "free_mask": torch.zeros(n, dtype=torch.bool, device=dev),
             "valid_mask": torch.ones(n, dtype=torch.bool, device=dev)}
     fx = 1000.0 * W / 1920.0
-    cam = Camera(W, H, fx, fx, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, torch.eye(4, dtype=torch.float64), device=dev)
+    T_cw = torch.eye(4, dtype=torch.float64)
+    world, rank = exchange if exchange else (1, 0)
+    if world > 1:      # the cameras of a rig: same position, yawed 25 degrees apart around the vertical (y) axis
+        a = _m.radians(25.0 * (rank - 0.5 * (world - 1)))
+        T_cw[0, 0], T_cw[0, 2], T_cw[2, 0], T_cw[2, 2] = _m.cos(a), -_m.sin(a), _m.sin(a), _m.cos(a)
+    cam = Camera(W, H, fx, fx, W / 2 - 0.5, H / 2 - 0.5, 0.05, 110.0, T_cw, device=dev)
     bg = torch.ones(3, device=dev)
     gd = torch.Generator(device=dev).manual_seed(9)
     gt_rgb = torch.rand(3, H, W, generator=gd, device=dev)
     gt_depth = 2.0 + 40.0 * torch.rand(1, H, W, generator=gd, device=dev)
     sky = torch.rand(1, H, W, generator=gd, device=dev) < 0.1
-    leaves = [geo, cfe] + [p for d in decs.values() for p in d.parameters()] + \
-             [cam.exposure_mat, cam.exposure_offset, cam.cam_rot_delta, cam.cam_trans_delta]
+    dec_params = [p for d in decs.values() for p in d.parameters()]
+    per_view = [cam.exposure_mat, cam.exposure_offset, cam.cam_rot_delta, cam.cam_trans_delta]   # stay local (tools.py:291-337)
+    leaves = [geo, cfe] + per_view + ([] if world > 1 else dec_params)
     info = {}
+    bucket = ex = None
+    if world > 1:
+        from pings_amd import dist as pdist
+
+        bucket = pdist.GradBucket(dec_params, overlap=True)      # p.grad become views of ONE flat buffer, hooks armed
+        ex = pdist.RowSparseExchange()
 
     def step():
         for p_ in leaves:
             p_.grad = None
+        if bucket is not None:
+            bucket.zero(1)                                        # one backward pass (one view) on this rank
         pkg = render(cam, None, data, decs, None, bg, view_concat_on=True, learn_color_residual=True, d2n_on=True,
                      gs_type="gaussian_surfel")
-        il = image_losses(pkg["render"], gt_rgb, pkg["surf_depth"], gt_depth, pkg["rend_alpha"], pkg["rend_normal"],
-                          pkg["surf_normal"], sky, depth_min=0.3, depth_max=80.0, depth_min_accu_alpha=0.4)
-        ssim = fused_ssim(pkg["render"].unsqueeze(0), gt_rgb.unsqueeze(0))
-        loss = 0.8 * il.rgb_l1 + 0.2 * (1.0 - ssim) + 0.5 * il.depth_l1 + 0.05 * il.normal_depth_consist + 0.1 * il.sky
-        loss.backward()
-        info["gaussians"] = int(pkg["gaussian_xyz"].shape[0])
-        info["visible_ratio"] = pkg["visible_neural_point_ratio"]
+        if pkg is not None:       # (None = a view that sees fewer than ten neural points, gaussian_renderer:224-292: such
+            # a rank still takes part in the exchange below, with no rows)
+            il = image_losses(pkg["render"], gt_rgb, pkg["surf_depth"], gt_depth, pkg["rend_alpha"], pkg["rend_normal"],
+                              pkg["surf_normal"], sky, depth_min=0.3, depth_max=80.0, depth_min_accu_alpha=0.4)
+            ssim = fused_ssim(pkg["render"].unsqueeze(0), gt_rgb.unsqueeze(0))
+            loss = 0.8 * il.rgb_l1 + 0.2 * (1.0 - ssim) + 0.5 * il.depth_l1 + 0.05 * il.normal_depth_consist + 0.1 * il.sky
+            loss.backward()                                       # world > 1: the decoder bucket's all-reduce starts in here
+            info["gaussians"] = int(pkg["gaussian_xyz"].shape[0])
+            info["visible_ratio"] = pkg["visible_neural_point_ratio"]
+        elif bucket is not None:
+            bucket.skip_backward()                                # keep the collective order: bucket, then rows
+        if ex is not None:
+            # rows of the [n + 1, 48] feature-gradient table this view wrote: the neural points it decoded (mapper.py:1581-1584)
+            zg = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)
+            tab = torch.cat([zg(geo), zg(cfe)], 1)
+            rows = torch.nonzero(tab.abs().amax(1) > 0).flatten()   # the count is a host value: it sizes the gather
+            ex.reduce_(tab, rows)
+            geo.grad, cfe.grad = tab[:, :32], tab[:, 32:]
+            bucket.finish()                                       # before opt.step()
+            info["exchange"] = dict(ex.last)
 
     step()
     _lib.sync_counts(reset=True)
     step()
     syncs = _lib.sync_counts(reset=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
     t = _timeit(step, steps, warmup)
+    if world > 1:
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = tt.item()
+        bucket.close()
+        return {"width": W, "height": H, "neural_points": n, "views": world, "gaussians_rasterised_rank0": info.get("gaussians", 0),
+                "ms_per_step": round(t * 1e3, 4), "Mpix_s_all_views": round(world * W * H / t / 1e6, 1),
+                "exchange": info.get("exchange"),
+                "bucket": "GradBucket(overlap=True).zero(1): the decoders' all-reduce is launched by the post-accumulate "
+                          "hook inside loss.backward(); finish() before the optimiser step",
+                "feature_rows": "RowSparseExchange on the [n + 1, 48] table of the real spawn / decoder adjoint"}
     pr = _prof_run(L, step, max(2, steps // 4))
     groups = {"decoders_fwd": ("mlp_fwd",), "decoders_bwd": ("mlp_bwd",), "ssim": ("ssim_fwd", "ssim_bwd"),
               "image_losses": ("image_losses_fwd", "image_losses_bwd")}
@@ -1073,15 +1144,18 @@ def main():
                       (24, 128), (24,), (128, 32), (128,), (8, 128), (8,), (128, 19), (128,), (24, 128), (24,),
                       (64, 35), (64,), (1, 64), (1,)]
         mlp_params = [torch.nn.Parameter(torch.zeros(*sh, device=dev)) for sh in mlp_shapes]
-        b_mlp = pdist.GradBucket(mlp_params, overlap=False)
+        b_mlp = pdist.GradBucket(mlp_params, overlap=True)   # hooked: p.grad are views of one flat buffer
         ex = pdist.RowSparseExchange()
 
     def exchange(radii):
-        b_mlp.zero()
+        b_mlp.zero(1)                                       # one backward pass reaches the decoders on this rank
         g14 = torch.cat([params[0].grad, params[1].grad, params[2].grad, params[3].grad, params[4].grad], 1)
         g_np = g14[own].view(n_np, 8, 14).sum(1)
-        b_mlp.flat.add_(g_np.mean())
-        b_mlp._launch()                                     # decoder bucket travels while the table is compacted
+        # the decoders' gradients arrive through AUTOGRAD (a stand-in for the spawn adjoint, which `render_step_exchange`
+        # runs for real): every parameter receives g_np.mean() from one backward pass, each accumulation runs the bucket's
+        # post-accumulate hook and the LAST one launches the asynchronous all-reduce — the public path, no private call
+        torch.autograd.backward([sum(p_.sum() for p_ in mlp_params)], [g_np.mean().detach()])
+        # ... so the decoder bucket travels while the table is compacted
         seen = (radii[own].view(n_np, 8) > 0).any(1)
         local = torch.nonzero(seen).flatten()               # the count sizes the gather (`render` reads it back anyway)
         rows = local + rank * n_np
@@ -1160,6 +1234,18 @@ def main():
     elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * W * H / (elapsed / args.steps) / 1e6
+
+    # N > 1: the real multi-view mapping step (every rank takes part: collectives inside), VERDICT r3 #7
+    rse = None
+    if world > 1 and not args.no_sdf:
+        try:
+            rse = bench_render_step(dev, max(args.steps // 2, 5), 2, exchange=(world, rank))
+        except Exception as e:  # noqa: BLE001
+            rse = {"error": f"{type(e).__name__}: {e}"}
+        for p_ in params:
+            p_.grad = None
+        torch.cuda.empty_cache()
+        dist.barrier()
 
     if rank == 0:
         # instance count of this view (for the algorithmic-bytes figures)
@@ -1262,7 +1348,26 @@ def main():
             leg("raster_c3_cloud", lambda: bench_raster_workload(
                 dev, "SURVEY 8d cloud at the C3 shape, 1M Gaussians, 1392x512",
                 synth_cloud(1_000_000, 1392, 512, 725.0, 725.0, dev, seed=42), 1392, 512, 725.0, ks, kw))
+
+            def rect_leg(rule):
+                # the headline workload under another tile-rectangle rule (csrc/raster_fwd.hip:preprocess_kernel): the
+                # published square without the lossless trimming, and the truncating box rounds 1-3 were timed on
+                prev = os.environ.get("PINGS_RASTER_RECT")
+                os.environ["PINGS_RASTER_RECT"] = rule
+                try:
+                    return bench_raster_workload(dev, f"headline cloud, PINGS_RASTER_RECT={rule}",
+                                                 synth_cloud(P, W, H, fx, fy, dev, seed=42), W, H, fx, ks, kw)
+                finally:
+                    if prev is None:
+                        os.environ.pop("PINGS_RASTER_RECT", None)
+                    else:
+                        os.environ["PINGS_RASTER_RECT"] = prev
+
+            leg("raster_rect_3sigma", lambda: rect_leg("3sigma"))
+            leg("raster_rect_ellipse", lambda: rect_leg("ellipse"))
             leg("render_step", lambda: bench_render_step(dev, ks, kw))
+            if rse is not None:
+                extras["render_step_exchange"] = rse
             leg("decoder", lambda: bench_decoder(dev, ks, kw))
             leg("map_maintenance", lambda: bench_map(dev, with_cpu=not args.no_cpu_baseline))
             leg("image_losses", lambda: bench_image_losses(dev, ks, kw, with_cpu=not args.no_cpu_baseline))
@@ -1279,6 +1384,12 @@ def main():
                                       "camera of the rig sees its own sector of the local map) + all-reduce of the six "
                                       "decoder MLPs" if world > 1 else ""),
                        "exchange": (ex.last if ex is not None else None),
+                       "rect_rule": {"tight": "tight: published 3-sigma tile square minus the tiles in which no pixel can "
+                                              "pass alpha >= 1/255 (output-identical to the square; legs raster_rect_3sigma / "
+                                              "raster_rect_ellipse time the other two rules)",
+                                     "3sigma": "3sigma: published 3DGS tile square",
+                                     "ellipse": "ellipse: truncating alpha-ellipse box of rounds 1-3 (NOT output-identical)"}[
+                           {"3": "3sigma", "e": "ellipse"}.get(os.environ.get("PINGS_RASTER_RECT", "t")[:1], "tight")],
                        "gaussians": P, "width": W, "height": H, "instances": int(I), "instances_blended": I_proc,
                        "visible_gaussians": int((radii > 0).sum().item()),
                        "mean_list_len_per_tile": round(I / (math.ceil(W / 16) * math.ceil(H / 16)), 1)},

@@ -33,7 +33,9 @@
 
 /* ------------------------------------------------------------------ general */
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change).  A binding compares pings_abi_version() of the
+ * library it loaded with the PINGS_ABI_VERSION of the header it was written against (pings_amd/_lib.py does). */
+#define PINGS_ABI_VERSION 7
 PINGS_API int pings_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). Host string. */
 PINGS_API const char* pings_last_error(void);
@@ -595,13 +597,18 @@ PINGS_API int pings_voxel_downsample_min_value(const float* points, const float*
  *                         pose_is_f64 (the quaternion part is then evaluated in float64 and cast, as the reference's
  *                         type promotion does) else float32
  *   pings_map_rehash      table[:] = -1; table[hash(points[v_j])] = v_j with v_j = sample_idx[j] (NULL: j) for
- *                         j < M, duplicates: the last j wins (:949-1000); slot_scratch: M int64 */
-PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int32_t cur_ts, const int32_t* point_ts_update,
-                                   const float* point_certainties, float diff_travel_dist_local,
-                                   float prune_certainty_thre, uint8_t* prune_mask, void* stream);
+ *                         j < M, duplicates: the last j wins (:949-1000); slot_scratch: M int64
+ * Timestamps index travel_dist[num_travel] / pose_diff[num_poses] with python semantics (negative wraps); one outside
+ * [-T, T) is an IndexError in the reference: the kernels never read out of bounds — they set bit 0 of the device
+ * word `out_of_range` (nullable; the caller zeroes it and reads it with its next read-back) and keep / do not move
+ * that point.  cur_ts outside [0, num_travel) is PINGS_ERR_ARG. */
+PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int64_t num_travel, int32_t cur_ts,
+                                   const int32_t* point_ts_update, const float* point_certainties,
+                                   float diff_travel_dist_local, float prune_certainty_thre, uint8_t* prune_mask,
+                                   int32_t* out_of_range, void* stream);
 PINGS_API int pings_map_adjust(int64_t N, float* neural_points, float* point_orientations, const int32_t* point_ts_create,
                                const int32_t* point_ts_update, int32_t use_mid_ts, const void* pose_diff,
-                               int32_t pose_is_f64, int64_t num_poses, void* stream);
+                               int32_t pose_is_f64, int64_t num_poses, int32_t* out_of_range, void* stream);
 PINGS_API int pings_map_rehash(const float* neural_points, const int64_t* sample_idx, int64_t M, float resolution,
                                int64_t buffer_size, int64_t* table, int64_t* slot_scratch, void* stream);
 PINGS_API size_t pings_map_update_scratch_bytes(int64_t M, int64_t num_points);
@@ -710,5 +717,17 @@ PINGS_API int pings_reg_normal_equations(const float* points, const float* sdf_g
  * t = N^-1 g in fp64 (Gaussian elimination with partial pivoting), T[4,4] = [expmap(t[:3]) | t[3:]] row-major fp64;
  * t_out[6] optional.  One tiny kernel instead of ~30 torch launches and the host sync of linalg.inv. */
 PINGS_API int pings_reg_solve(const float* normal_eq, float lm_lambda, double* T_out, double* t_out, void* stream);
+/* The same step with a conditioning report.  The reference's `torch.linalg.inv` (utils/tracker.py:668) raises on a
+ * singular N; the kernel above cannot raise, so it leaves a bit mask in the device word `status_dev`:
+ *   PINGS_REG_SINGULAR         a pivot of the damped matrix is exactly 0 or not finite (the case the reference raises on)
+ *   PINGS_REG_ILL_CONDITIONED  smallest |pivot| < 1e-7 x largest |entry|: the step is rounding noise (N arrives in fp32)
+ *   PINGS_REG_NONFINITE        t or T came out Inf / NaN
+ * `status_host` (optional, host memory): the call waits for the kernel with a polled read-back and copies the word —
+ * the one synchronisation the reference has at this line as well. */
+#define PINGS_REG_SINGULAR 1
+#define PINGS_REG_ILL_CONDITIONED 2
+#define PINGS_REG_NONFINITE 4
+PINGS_API int pings_reg_solve_checked(const float* normal_eq, float lm_lambda, double* T_out, double* t_out,
+                                      int32_t* status_dev, int32_t* status_host, void* stream);
 
 #endif /* PINGS_HIP_H_ */

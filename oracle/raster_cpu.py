@@ -69,7 +69,7 @@ class Settings:
     prcppoint: torch.Tensor = None       # [2] = (cx/W, cy/H) (cameras.py:61); None -> centre
     front_only: bool = True              # config[4] (gaussian_renderer/__init__.py:142)
     mode: str = "surfel"                 # "surfel" | "3dgs"
-    rect: str = "ellipse"                # tile rectangle: "ellipse" (default, DESIGN §3 assumption 1) | "3sigma" (published 3DGS square)
+    rect: str = "tight"                  # tile rectangle: "tight" (default: published square, tiles no pixel can pass the alpha test in removed) | "3sigma" (published 3DGS square) | "ellipse" (rounds 1-3, truncating)
     mark_frustum: bool = True            # markVisible: depth AND |ndc| <= 1.3 (assumption 2) | False: depth only
 
 
@@ -173,35 +173,60 @@ def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None, op
 
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     with torch.no_grad():
-        # Tile rectangle = axis-aligned bounding box of the footprint ellipse, cut at 3 sigma and at the
-        # radius where alpha falls below 1/255:  k^2 = min(9, 2 ln(255 o));  ex = k sqrt(cov_xx), ey = k sqrt(cov_yy).
-        # A Gaussian whose peak alpha is below 1/255 touches nothing.
+        # Tile rectangle, three rules (Settings.rect; csrc/raster_fwd.hip:preprocess_kernel follows the same op order):
+        #   "3sigma"  the published 3DGS getRect(): square of half-width ceil(3 sqrt(lambda_max)), upper bound
+        #             (m + r + TILE - 1) / TILE.
+        #   "tight"   (default) that square INTERSECTED with a box that contains every pixel whose alpha, as the blend
+        #             evaluates it in fp32, can reach 1/255: dx^2 <= thr / (sx (1 - 4e-6 cx / sx)), sx = cx - cy^2 / cz
+        #             taken 2e-6 cx low, thr = 2 ln(255 o) + 2e-3; an axis with cx / sx > 1e5 keeps the square.  The tiles
+        #             it drops hold no pixel that passes the alpha test: every output equals the "3sigma" rule's
+        #             (test_raster.py::test_oracle_tight_rectangle_is_lossless), radii included.
+        #   "ellipse" rounds 1-3: bounding box of the ellipse cut at k^2 = min(9, 2 ln(255 o)) — truncates the
+        #             alpha < ~0.011 tail (images differ by up to 3.4e-3); opt-in only.
+        rule = getattr(s, "rect", "tight")
         if opacities is None:
-            k2 = torch.full_like(mx, 9.0)
+            opd = torch.ones_like(mx)
         else:
-            k2 = torch.clamp(2.0 * torch.log(255.0 * opacities.reshape(-1).detach()), max=9.0)
+            opd = opacities.reshape(-1).detach()
+        k2 = torch.clamp(2.0 * torch.log(255.0 * opd), max=9.0)
         def _tile(v, hi):
             return torch.clamp(torch.floor(v / TILE), 0, hi).to(torch.int64)
-        sq = getattr(s, "rect", "ellipse") == "3sigma"
-        safe = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius)
-        if not sq:
-            safe = safe & (k2 > 0)
-        k2s = torch.where(safe, k2, torch.zeros_like(k2))
-        mxs = torch.where(safe, mx, torch.zeros_like(mx))
-        mys = torch.where(safe, my, torch.zeros_like(my))
-        if sq:
-            # the published 3DGS getRect(): square of half-width ceil(3 sqrt(lambda_max)), upper bound
-            # (m + r + TILE - 1) / TILE.  Selectable so that the deviation of the default stays measurable.
-            ex = ey = torch.where(safe, radius, torch.zeros_like(radius)).detach()
+        want = in_front & det_ok & torch.isfinite(mx) & torch.isfinite(my) & torch.isfinite(radius)
+        safe = want if rule == "3sigma" else want & (k2 > 0)
+        zero = torch.zeros_like(mx)
+        mxs = torch.where(want, mx, zero)
+        mys = torch.where(want, my, zero)
+        if rule in ("3sigma", "tight"):
+            ex = ey = torch.where(want, radius, zero).detach()
             up = TILE - 1
         else:
-            ex = torch.sqrt(k2s * torch.where(safe, cxx, torch.zeros_like(cxx)))
-            ey = torch.sqrt(k2s * torch.where(safe, cyy, torch.zeros_like(cyy)))
+            k2s = torch.where(safe, k2, zero)
+            ex = torch.sqrt(k2s * torch.where(safe, cxx, zero))
+            ey = torch.sqrt(k2s * torch.where(safe, cyy, zero))
             up = TILE
         xmin, xmax = _tile(mxs - ex, gx), _tile((mxs + ex) + up, gx)
         ymin, ymax = _tile(mys - ey, gy), _tile((mys + ey) + up, gy)
+        sq_valid = want & ((xmax - xmin) * (ymax - ymin) > 0)
+        if rule == "tight":
+            cxd, cyd, czd = conic_x.detach(), conic_y.detach(), conic_z.detach()
+            thr = 2.0 * torch.log(255.0 * opd) + 2e-3
+            sx = (cxd - (cyd * cyd) / czd) - 2e-6 * cxd
+            sy = (czd - (cyd * cyd) / cxd) - 2e-6 * czd
+            kx, ky = cxd / sx, czd / sy
+            usex = safe & (sx > 0) & (kx <= 1e5)
+            usey = safe & (sy > 0) & (ky <= 1e5)
+            one = torch.ones_like(mx)
+            bx = torch.sqrt(torch.where(usex, thr, zero) / torch.where(usex, sx * (1.0 - 4e-6 * kx), one)) * 1.000001 + 1e-3
+            by = torch.sqrt(torch.where(usey, thr, zero) / torch.where(usey, sy * (1.0 - 4e-6 * ky), one)) * 1.000001 + 1e-3
+            xmin = torch.where(usex, torch.maximum(xmin, _tile(mxs - bx, gx)), xmin)
+            xmax = torch.where(usex, torch.minimum(xmax, _tile((mxs + bx) + TILE, gx)), xmax)
+            ymin = torch.where(usey, torch.maximum(ymin, _tile(mys - by, gy)), ymin)
+            ymax = torch.where(usey, torch.minimum(ymax, _tile((mys + by) + TILE, gy)), ymax)
+            xmax = torch.maximum(xmax, xmin)
+            ymax = torch.maximum(ymax, ymin)
         tiles = (xmax - xmin) * (ymax - ymin)
         valid = safe & (tiles > 0)
+        rad_valid = sq_valid if rule == "tight" else valid
 
     out = dict(px=px, py=py, pz=pz, mx=mx, my=my, conic_x=conic_x, conic_y=conic_y, conic_z=conic_z,
                radius=radius, xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, valid=valid)
@@ -216,6 +241,7 @@ def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None, op
             back = q >= 0 if s.front_only else q > 0
         if s.front_only:
             valid = valid & ~back
+            rad_valid = rad_valid & ~back
         else:
             sgn = torch.where(back, -torch.ones_like(q), torch.ones_like(q))
             nx, ny, nz, q = nx * sgn, ny * sgn, nz * sgn, q * sgn
@@ -223,7 +249,8 @@ def preprocess(means3D, scales, rotations, s: Settings, theta=None, rho=None, op
         out.update(nx=nx, ny=ny, nz=nz, q=q, zlo=pz - rz, zhi=pz + rz, valid=valid)
     with torch.no_grad():
         out["tiles_touched"] = torch.where(out["valid"], tiles, torch.zeros_like(tiles))
-        out["radii"] = torch.where(out["valid"], radius, torch.zeros_like(radius)).to(torch.int32)
+        # `radii` follows the published square under "tight" as well: > 0 iff the square touches the image
+        out["radii"] = torch.where(rad_valid, radius, torch.zeros_like(radius)).to(torch.int32)
     return out
 
 

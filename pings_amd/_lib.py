@@ -38,6 +38,14 @@ def header_symbols() -> list[str]:
     return re.findall(r"PINGS_API\s+[\w\s\*]+?\b(pings_\w+)\s*\(", txt)
 
 
+def expected_abi() -> int:
+    """PINGS_ABI_VERSION of the header this package's ctypes signatures were written against."""
+    m = re.search(r"#define\s+PINGS_ABI_VERSION\s+(\d+)", HEADER.read_text())
+    if not m:
+        raise PingsHipError(f"{HEADER} does not define PINGS_ABI_VERSION")
+    return int(m.group(1))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -45,8 +53,15 @@ def lib() -> C.CDLL:
             raise PingsHipError(
                 f"{LIB_PATH} is missing: build it with `python -m pings_amd.build` "
                 "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
-        _lib = C.CDLL(str(LIB_PATH))
-        _declare(_lib)
+        l = C.CDLL(str(LIB_PATH))
+        _declare(l)
+        # a stale libpings_hip.so (or a PINGS_HIP_LIB A/B build of another revision) would be called with this
+        # package's argtypes: refuse it here instead of passing mismatched arguments into kernels
+        got, want = l.pings_abi_version(), expected_abi()
+        if got != want:
+            raise PingsHipError(f"{LIB_PATH} reports ABI version {got}, this package binds version {want} "
+                                f"(include/pings_hip.h): rebuild with `python -m pings_amd.build`")
+        _lib = l
     return _lib
 
 

@@ -89,7 +89,7 @@ int host_read_words(const uint32_t* const* dev_words, int n, uint32_t* out, hipS
   static thread_local ReadRecord* rec_dev = nullptr;
   static thread_local uint32_t counter = 0;
   if (!rec) {
-    PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&rec), sizeof(ReadRecord), hipHostMallocMapped));
+    PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&rec), sizeof(ReadRecord), hipHostMallocMapped | hipHostMallocPortable));
     PINGS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&rec_dev), rec, 0));
     rec->seq = 0;
   }
@@ -161,6 +161,6 @@ PINGS_API int pings_prof_report(char* buf, size_t cap) {
   return PINGS_OK;
 }
 
-PINGS_API int pings_abi_version(void) { return 6; }
+PINGS_API int pings_abi_version(void) { return PINGS_ABI_VERSION; }
 
 PINGS_API const char* pings_last_error(void) { return pings::g_err; }

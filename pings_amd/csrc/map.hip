@@ -396,13 +396,22 @@ inline unsigned blocks_for(i64 n) { return (unsigned)((n + 255) / 256 > 0 ? (n +
 
 // ------------------------------------------------------------------ loop-closure maintenance
 // prune_map (:871-909): prune = |travel[cur] - travel[ts_update]| > diff_travel  and  certainty < threshold
-__global__ __launch_bounds__(256) void prune_mask_kernel(i64 N, const float* __restrict__ travel, int cur_ts,
+// A timestamp outside [-T, T) is an IndexError in the reference; here it raises the caller's flag word (read with the
+// count the caller reads anyway) and the point is kept / left where it is — never an out-of-bounds read.
+__global__ __launch_bounds__(256) void prune_mask_kernel(i64 N, const float* __restrict__ travel, i64 T, int cur_ts,
                                                          const int32_t* __restrict__ ts_update,
                                                          const float* __restrict__ cert, float diff_travel, float thre,
-                                                         uint8_t* __restrict__ prune) {
+                                                         uint8_t* __restrict__ prune, int32_t* __restrict__ oob) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float d = fabsf(travel[cur_ts] - travel[ts_update[i]]);
+  i64 ts = ts_update[i];
+  if (ts < 0) ts += T;                                       // python indexing
+  if (ts < 0 || ts >= T) {
+    if (oob) atomicOr(oob, 1);
+    prune[i] = 0;
+    return;
+  }
+  const float d = fabsf(travel[cur_ts] - travel[ts]);
   prune[i] = (d > diff_travel && cert[i] < thre) ? 1 : 0;
 }
 
@@ -413,11 +422,15 @@ template <typename PT>
 __global__ __launch_bounds__(256) void adjust_kernel(i64 N, float* __restrict__ pts, float* __restrict__ quat,
                                                      const int32_t* __restrict__ ts_create,
                                                      const int32_t* __restrict__ ts_update, int use_mid_ts,
-                                                     const PT* __restrict__ pose, i64 T) {
+                                                     const PT* __restrict__ pose, i64 T, int32_t* __restrict__ oob) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   i64 ts = use_mid_ts ? (i64)(int32_t)((float)(ts_create[i] + ts_update[i]) / 2.0f) : (i64)ts_create[i];
   if (ts < 0) ts += T;                                       // python indexing
+  if (ts < 0 || ts >= T) {                                   // the reference's index error: flagged, point not moved
+    if (oob) atomicOr(oob, 1);
+    return;
+  }
   const PT* M = pose + 16 * ts;
   const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
 #pragma unroll
@@ -460,23 +473,26 @@ __global__ __launch_bounds__(256) void rehash_unpack_kernel(i64 M, const i64* __
 
 }  // namespace
 
-PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int32_t cur_ts, const int32_t* point_ts_update,
-                                   const float* point_certainties, float diff_travel_dist_local,
-                                   float prune_certainty_thre, uint8_t* prune_mask, void* stream) {
+PINGS_API int pings_map_prune_mask(int64_t N, const float* travel_dist, int64_t num_travel, int32_t cur_ts,
+                                   const int32_t* point_ts_update, const float* point_certainties,
+                                   float diff_travel_dist_local, float prune_certainty_thre, uint8_t* prune_mask,
+                                   int32_t* out_of_range, void* stream) {
   PINGS_ARG_CHECK(N >= 0, "negative N");
   if (N == 0) return PINGS_OK;
-  PINGS_ARG_CHECK(travel_dist && point_ts_update && point_certainties && prune_mask && cur_ts >= 0, "bad argument");
+  PINGS_ARG_CHECK(travel_dist && point_ts_update && point_certainties && prune_mask, "bad argument");
+  PINGS_ARG_CHECK(num_travel > 0 && cur_ts >= 0 && cur_ts < num_travel, "cur_ts outside travel_dist");
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope sc("map_prune_mask", st);
-  prune_mask_kernel<<<blocks_for(N), 256, 0, st>>>(N, travel_dist, cur_ts, point_ts_update, point_certainties,
-                                                   diff_travel_dist_local, prune_certainty_thre, prune_mask);
+  prune_mask_kernel<<<blocks_for(N), 256, 0, st>>>(N, travel_dist, num_travel, cur_ts, point_ts_update,
+                                                   point_certainties, diff_travel_dist_local, prune_certainty_thre,
+                                                   prune_mask, out_of_range);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
 
 PINGS_API int pings_map_adjust(int64_t N, float* neural_points, float* point_orientations, const int32_t* point_ts_create,
                                const int32_t* point_ts_update, int32_t use_mid_ts, const void* pose_diff,
-                               int32_t pose_is_f64, int64_t num_poses, void* stream) {
+                               int32_t pose_is_f64, int64_t num_poses, int32_t* out_of_range, void* stream) {
   PINGS_ARG_CHECK(N >= 0 && num_poses > 0, "bad sizes");
   if (N == 0) return PINGS_OK;
   PINGS_ARG_CHECK(neural_points && point_orientations && point_ts_create && pose_diff, "null pointer");
@@ -485,10 +501,12 @@ PINGS_API int pings_map_adjust(int64_t N, float* neural_points, float* point_ori
   pings::prof::Scope sc("map_adjust", st);
   if (pose_is_f64)
     adjust_kernel<double><<<blocks_for(N), 256, 0, st>>>(N, neural_points, point_orientations, point_ts_create,
-                                                         point_ts_update, use_mid_ts, (const double*)pose_diff, num_poses);
+                                                         point_ts_update, use_mid_ts, (const double*)pose_diff, num_poses,
+                                                         out_of_range);
   else
     adjust_kernel<float><<<blocks_for(N), 256, 0, st>>>(N, neural_points, point_orientations, point_ts_create,
-                                                        point_ts_update, use_mid_ts, (const float*)pose_diff, num_poses);
+                                                        point_ts_update, use_mid_ts, (const float*)pose_diff, num_poses,
+                                                        out_of_range);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

@@ -44,6 +44,8 @@ constexpr uint16_t OCC_ALL = 0xFFFFu;
 
 constexpr int MODE_SURFEL = 0;
 constexpr int MODE_3DGS = 1;
+// tile-rectangle rule of preprocess_kernel (raster_fwd.hip)
+constexpr int RECT_TIGHT = 0, RECT_3SIGMA = 1, RECT_ELLIPSE = 2;
 
 // 16 floats of per-instance gradient accumulated by the blend backward pass
 // (one 64-B row per (tile, Gaussian) instance, summed per Gaussian afterwards).

@@ -38,7 +38,7 @@ struct KParams {
   int P, W, H, gx, gy;
   int front_only;
   float occ_amin;    // smallest per-tile alpha bound that is worth an occlusion-budget entry (see preprocess_kernel)
-  int rect_3sigma;   // PINGS_RASTER_RECT=3sigma: the published 3DGS tile square (A/B: measures what the ellipse box drops)
+  int rect_rule;     // RECT_TIGHT (default) | RECT_3SIGMA | RECT_ELLIPSE, see preprocess_kernel (PINGS_RASTER_RECT)
   float fx, fy, limx, limy, scale_mod;
   const float* view;
   const float* proj_raw;
@@ -270,48 +270,87 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     rz = 3.0f * fmaxf(S0, S1);
   }
 
-  // tile rectangle: bounding box of the footprint ellipse, cut at 3 sigma and at alpha = 1/255
+  // Tile rectangle.  Three rules (KParams::rect_rule, PINGS_RASTER_RECT):
+  //   RECT_3SIGMA   the published 3DGS getRect(): the square of half-width ceil(3 sqrt(lambda_max)) around the centre,
+  //                 upper bound (m + r + TILE - 1) / TILE.
+  //   RECT_TIGHT    (default) that square INTERSECTED with the bounding box of the region in which the blend kernels'
+  //                 own fp32 evaluation of alpha can reach 1/255.  A tile outside that box holds no pixel that passes
+  //                 the alpha test, so dropping it changes no output bit: images, per-Gaussian sums and gradients equal
+  //                 RECT_3SIGMA's (tests/test_raster.py::test_default_rectangle_is_lossless).  `radii` is the published
+  //                 one: a Gaussian whose square touches the image keeps radius > 0 even if no tile is left.
+  //   RECT_ELLIPSE  rounds 1-3: bounding box of the ellipse cut at min(3 sigma, alpha = 1/255) — drops the
+  //                 alpha < ~0.011 tail the published rule blends (images differ by up to 3.4e-3); opt-in only.
+  // Box of RECT_TIGHT: with the conic (cx, cy, cz) the kernels read, q(d) = cx dx^2 + 2 cy dx dy + cz dy^2 >= sx dx^2,
+  // sx = cx - cy^2 / cz (Schur complement; = 1 / cov_xx in exact arithmetic), and the kernels' evaluation q^ of q is
+  // off by at most 1e-6 S, S = cx dx^2 + 2 |cy dx dy| + cz dy^2 <= 4 (cx / sx) q (seven roundings of relative 6e-8 on
+  // each term; 1e-6 leaves a factor two).  A pixel passes only if q^ <= thr = 2 ln(255 o) (+ 2e-3 for the fast exp /
+  // log), hence only if dx^2 <= thr / (sx (1 - 4e-6 cx / sx)).  sx is taken 2e-6 cx low (its own three roundings); a
+  // footprint so thin that cx / sx > 1e5 (or a non-finite / non-positive sx) keeps the whole square on that axis.
   const float opac = opacities[g];
   const float k2 = fminf(2.0f * logf(255.0f * opac), 9.0f);
-  ok = ok && (k2 > 0.0f || p.rect_3sigma);
-  if (ok) {
-    // default: bounding box of the ellipse; rect_3sigma: the square of half-width ceil(3 sqrt(lambda_max)) of the
-    // published 3DGS getRect(), upper bound (m + r + TILE - 1) / TILE
-    const float ex = p.rect_3sigma ? radius : sqrtf(k2 * cxx), ey = p.rect_3sigma ? radius : sqrtf(k2 * cyy);
-    const float up = p.rect_3sigma ? (float)(TILE - 1) : (float)TILE;
+  const bool want = ok;                 // survives culling: `radii` of the published rule depends on the square only
+  ok = ok && (k2 > 0.0f || p.rect_rule == RECT_3SIGMA);
+  if (want) {
+    const bool square = p.rect_rule != RECT_ELLIPSE;
+    const float ex = square ? radius : sqrtf(k2 * cxx), ey = square ? radius : sqrtf(k2 * cyy);
+    const float up = square ? (float)(TILE - 1) : (float)TILE;
     const float fgx = (float)p.gx, fgy = (float)p.gy;
-    const int xmin = (int)fminf(fmaxf(floorf((mx - ex) / (float)TILE), 0.0f), fgx);
-    const int xmax = (int)fminf(fmaxf(floorf(((mx + ex) + up) / (float)TILE), 0.0f), fgx);
-    const int ymin = (int)fminf(fmaxf(floorf((my - ey) / (float)TILE), 0.0f), fgy);
-    const int ymax = (int)fminf(fmaxf(floorf(((my + ey) + up) / (float)TILE), 0.0f), fgy);
-    const int tiles = (xmax - xmin) * (ymax - ymin);
-    if (tiles > 0) {
-      key = __float_as_uint(pz);
-      // rect.x: the INNER rectangle of the occlusion-budget pass, as four 8-bit margins inside the tile rectangle
-      // (left, right, top, bottom; margins that meet = empty).  A tile adds to the budget only if all of its pixels
-      // pass the alpha test (tile_min_alpha > 0), i.e. its four corners lie inside the alpha >= 1/255 ellipse, hence
-      // inside that ellipse's bounding box [m - e', m + e'], e' = sqrt(thr cov) with the UNCAPPED thr = 2 ln(255 o)
-      // (the tile rectangle itself is cut at 3 sigma).  Typically the rectangle shrinks by a tile on every side —
-      // half the pairs of a 7 x 7 rectangle.  The bounds are widened by 0.02 tile against rounding; a Gaussian whose
-      // minor semi-axis sqrt(thr lambda_min) is below 7.5 px (threshold 50 = 7.07^2: slack again) cannot hold the
-      // 15 x 15 pixel square of a tile at all.
-      const float thr_u = 2.0f * logf(opac / p.occ_amin);
-      const float lam_min = mid - sqrtf(fmaxf(mid * mid - det, 0.0f));
-      uint32_t inner = 0xFFFFFFFFu;   // empty
-      if (thr_u * lam_min >= 50.0f) {
-        const float exu = sqrtf(thr_u * cxx), eyu = sqrtf(thr_u * cyy);
-        const int ix0 = max(xmin, (int)ceilf((mx - exu) / (float)TILE - 0.02f));
-        const int ix1 = min(xmax, (int)floorf((mx + exu - 15.0f) / (float)TILE + 0.02f) + 1);
-        const int iy0 = max(ymin, (int)ceilf((my - eyu) / (float)TILE - 0.02f));
-        const int iy1 = min(ymax, (int)floorf((my + eyu - 15.0f) / (float)TILE + 0.02f) + 1);
-        if (ix1 > ix0 && iy1 > iy0)
-          inner = (uint32_t)min(ix0 - xmin, 255) | ((uint32_t)min(xmax - ix1, 255) << 8) |
-                  ((uint32_t)min(iy0 - ymin, 255) << 16) | ((uint32_t)min(ymax - iy1, 255) << 24);
+    int xmin = (int)fminf(fmaxf(floorf((mx - ex) / (float)TILE), 0.0f), fgx);
+    int xmax = (int)fminf(fmaxf(floorf(((mx + ex) + up) / (float)TILE), 0.0f), fgx);
+    int ymin = (int)fminf(fmaxf(floorf((my - ey) / (float)TILE), 0.0f), fgy);
+    int ymax = (int)fminf(fmaxf(floorf(((my + ey) + up) / (float)TILE), 0.0f), fgy);
+    const bool sq_tiles = (xmax - xmin) * (ymax - ymin) > 0;
+    if (p.rect_rule == RECT_TIGHT) {
+      if (sq_tiles) rad = (int)radius;
+      if (ok) {
+        const float thr = 2.0f * logf(255.0f * opac) + 2e-3f;
+        const float sx = (conic_x - (conic_y * conic_y) / conic_z) - 2e-6f * conic_x;
+        const float sy = (conic_z - (conic_y * conic_y) / conic_x) - 2e-6f * conic_z;
+        const float kx = conic_x / sx, ky = conic_z / sy;
+        if (sx > 0.0f && kx <= 1e5f) {   // NaN -> keep the square
+          const float bx = sqrtf(thr / (sx * (1.0f - 4e-6f * kx))) * 1.000001f + 1e-3f;
+          xmin = max(xmin, (int)fminf(fmaxf(floorf((mx - bx) / (float)TILE), 0.0f), fgx));
+          xmax = min(xmax, (int)fminf(fmaxf(floorf(((mx + bx) + (float)TILE) / (float)TILE), 0.0f), fgx));
+        }
+        if (sy > 0.0f && ky <= 1e5f) {
+          const float by = sqrtf(thr / (sy * (1.0f - 4e-6f * ky))) * 1.000001f + 1e-3f;
+          ymin = max(ymin, (int)fminf(fmaxf(floorf((my - by) / (float)TILE), 0.0f), fgy));
+          ymax = min(ymax, (int)fminf(fmaxf(floorf(((my + by) + (float)TILE) / (float)TILE), 0.0f), fgy));
+        }
+        xmax = max(xmax, xmin);
+        ymax = max(ymax, ymin);
       }
-      const uint32_t covers = inner;
-      rc = make_uint4(covers, (uint32_t)xmin | ((uint32_t)ymin << 16),
-                      (uint32_t)xmax | ((uint32_t)ymax << 16), (uint32_t)tiles);
-      rad = (int)radius;
+    }
+    if (ok) {
+      const int tiles = (xmax - xmin) * (ymax - ymin);
+      if (tiles > 0) {
+        key = __float_as_uint(pz);
+        // rect.x: the INNER rectangle of the occlusion-budget pass, as four 8-bit margins inside the tile rectangle
+        // (left, right, top, bottom; margins that meet = empty).  A tile adds to the budget only if all of its pixels
+        // pass the alpha test (tile_min_alpha > 0), i.e. its four corners lie inside the alpha >= 1/255 ellipse, hence
+        // inside that ellipse's bounding box [m - e', m + e'], e' = sqrt(thr cov) with the UNCAPPED thr = 2 ln(255 o)
+        // (the tile rectangle itself is cut at 3 sigma).  Typically the rectangle shrinks by a tile on every side —
+        // half the pairs of a 7 x 7 rectangle.  The bounds are widened by 0.02 tile against rounding; a Gaussian whose
+        // minor semi-axis sqrt(thr lambda_min) is below 7.5 px (threshold 50 = 7.07^2: slack again) cannot hold the
+        // 15 x 15 pixel square of a tile at all.
+        const float thr_u = 2.0f * logf(opac / p.occ_amin);
+        const float lam_min = mid - sqrtf(fmaxf(mid * mid - det, 0.0f));
+        uint32_t inner = 0xFFFFFFFFu;   // empty
+        if (thr_u * lam_min >= 50.0f) {
+          const float exu = sqrtf(thr_u * cxx), eyu = sqrtf(thr_u * cyy);
+          const int ix0 = max(xmin, (int)ceilf((mx - exu) / (float)TILE - 0.02f));
+          const int ix1 = min(xmax, (int)floorf((mx + exu - 15.0f) / (float)TILE + 0.02f) + 1);
+          const int iy0 = max(ymin, (int)ceilf((my - eyu) / (float)TILE - 0.02f));
+          const int iy1 = min(ymax, (int)floorf((my + eyu - 15.0f) / (float)TILE + 0.02f) + 1);
+          if (ix1 > ix0 && iy1 > iy0)
+            inner = (uint32_t)min(ix0 - xmin, 255) | ((uint32_t)min(xmax - ix1, 255) << 8) |
+                    ((uint32_t)min(iy0 - ymin, 255) << 16) | ((uint32_t)min(ymax - iy1, 255) << 24);
+        }
+        const uint32_t covers = inner;
+        rc = make_uint4(covers, (uint32_t)xmin | ((uint32_t)ymin << 16),
+                        (uint32_t)xmax | ((uint32_t)ymax << 16), (uint32_t)tiles);
+        rad = (int)radius;
+      }
     }
   }
   depth_key[g] = key;
@@ -2036,7 +2075,7 @@ static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   kp.gx = ceil_div(kp.W, TILE);
   kp.gy = ceil_div(kp.H, TILE);
   kp.front_only = s->front_only;
-  kp.rect_3sigma = 0;
+  kp.rect_rule = RECT_TIGHT;
   // Tiles a Gaussian covers with less than this alpha everywhere are left out of the occlusion budget: fewer entries
   // is still a lower bound of the opacity in front (conservative: the kept lists can only grow, results unchanged),
   // and the faint rim of every footprint was most of the budget pass's atomics.  Metric-1 sweep (r03): 1/255 -> 0.15
@@ -2044,7 +2083,7 @@ static int make_params(const pings_raster_settings* s, int P, KParams& kp) {
   // 0.005 ms); C2 / C3 unchanged.  PINGS_OCC_AMIN overrides (1/255 = every covered tile, the round-2 behaviour).
   kp.occ_amin = 0.15f;
   if (const char* e = getenv("PINGS_OCC_AMIN")) kp.occ_amin = fminf(fmaxf((float)atof(e), 1.0f / 255.0f), 0.99f);
-  if (const char* e = getenv("PINGS_RASTER_RECT")) kp.rect_3sigma = e[0] == '3';
+  if (const char* e = getenv("PINGS_RASTER_RECT")) kp.rect_rule = e[0] == '3' ? RECT_3SIGMA : e[0] == 'e' ? RECT_ELLIPSE : RECT_TIGHT;
   kp.fx = (float)((double)kp.W / (2.0 * s->tanfovx));
   kp.fy = (float)((double)kp.H / (2.0 * s->tanfovy));
   kp.limx = (float)(1.3 * s->tanfovx);
@@ -2158,7 +2197,7 @@ PINGS_API int pings_raster_preprocess_dyn(const pings_raster_settings* s, int P,
   static thread_local FrameSummary* host_sum_dev = nullptr;
   static thread_local uint32_t frame_seq = 0;
   if (!host_sum) {
-    PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_sum), sizeof(FrameSummary), hipHostMallocMapped));
+    PINGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_sum), sizeof(FrameSummary), hipHostMallocMapped | hipHostMallocPortable));
     PINGS_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_sum_dev), host_sum, 0));
     host_sum->seq = 0;
   }

@@ -78,14 +78,21 @@ __global__ void reg_finish_kernel(const double* __restrict__ partial, int nblock
 // in one single-thread kernel: the reference spends ~30 tiny torch launches and a host sync (linalg.inv checks its
 // info word) on it, 50-100 times per frame.  N is damped in fp32 like the reference's `N_mat += lambda diag(N_mat)`,
 // then everything is fp64: t = N^-1 g by Gaussian elimination with partial pivoting, R = I + S sin(a) + S^2 (1 - cos a).
+// status (optional device word): PINGS_REG_SINGULAR = a pivot is exactly zero or not finite — the case in which the
+// reference's torch.linalg.inv raises (utils/tracker.py:668; LAPACK getrf info > 0); PINGS_REG_ILL_CONDITIONED = the
+// smallest pivot is below 1e-7 (one fp32 ulp: N arrives rounded to fp32) of the largest entry of the damped matrix,
+// i.e. the step is decided by rounding noise; PINGS_REG_NONFINITE = t or the pose came out Inf / NaN.
 __global__ void reg_solve_kernel(const float* __restrict__ ng, float lm_lambda, double* __restrict__ T_out,
-                                 double* __restrict__ t_out) {
+                                 double* __restrict__ t_out, int32_t* __restrict__ status) {
   double A[6][7];
+  double scale = 0.0, min_piv = 1e300;
+  int flags = 0;
   for (int r = 0; r < 6; ++r) {
     for (int c = 0; c < 6; ++c) {
       float v = ng[r * 6 + c];
       if (r == c) v += lm_lambda * v;
       A[r][c] = (double)v;
+      scale = fmax(scale, fabs((double)v));
     }
     A[r][6] = (double)ng[36 + r];
   }
@@ -95,6 +102,8 @@ __global__ void reg_solve_kernel(const float* __restrict__ ng, float lm_lambda, 
       if (fabs(A[r][k]) > fabs(A[piv][k])) piv = r;
     if (piv != k)
       for (int c = 0; c < 7; ++c) { const double t = A[k][c]; A[k][c] = A[piv][c]; A[piv][c] = t; }
+    if (A[k][k] == 0.0 || !isfinite(A[k][k])) flags |= PINGS_REG_SINGULAR;
+    min_piv = fmin(min_piv, fabs(A[k][k]));
     const double inv = 1.0 / A[k][k];
     for (int r = k + 1; r < 6; ++r) {
       const double f = A[r][k] * inv;
@@ -121,17 +130,41 @@ __global__ void reg_solve_kernel(const float* __restrict__ ng, float lm_lambda, 
   T_out[12] = 0.0; T_out[13] = 0.0; T_out[14] = 0.0; T_out[15] = 1.0;
   if (t_out)
     for (int r = 0; r < 6; ++r) t_out[r] = t[r];
+  if (status) {
+    if (!(min_piv >= 1e-7 * scale)) flags |= PINGS_REG_ILL_CONDITIONED;   // also when scale is NaN
+    bool fin = true;
+    for (int r = 0; r < 6; ++r) fin = fin && isfinite(t[r]);
+    // (t = 0 exactly makes the axis 0 / 0, as in the reference's expmap: reported as non-finite, not as singular)
+    for (int r = 0; r < 12; ++r) fin = fin && isfinite(T_out[r]);
+    if (!fin) flags |= PINGS_REG_NONFINITE;
+    *status = flags;
+  }
 }
 
 }  // namespace
 
-PINGS_API int pings_reg_solve(const float* normal_eq, float lm_lambda, double* T_out, double* t_out, void* stream) {
+PINGS_API int pings_reg_solve_checked(const float* normal_eq, float lm_lambda, double* T_out, double* t_out,
+                                      int32_t* status_dev, int32_t* status_host, void* stream) {
   PINGS_ARG_CHECK(normal_eq && T_out, "null pointer");
+  PINGS_ARG_CHECK(status_dev || !status_host, "status_host needs status_dev");
   hipStream_t st = pings::as_stream(stream);
-  pings::prof::Scope sc("reg_solve", st);
-  reg_solve_kernel<<<1, 1, 0, st>>>(normal_eq, lm_lambda, T_out, t_out);
-  PINGS_LAUNCH_CHECK();
+  {
+    pings::prof::Scope sc("reg_solve", st);
+    reg_solve_kernel<<<1, 1, 0, st>>>(normal_eq, lm_lambda, T_out, t_out, status_dev);
+    PINGS_LAUNCH_CHECK();
+  }
+  if (status_host) {   // the reference synchronises here as well (linalg.inv reads its info word)
+    const uint32_t* w[1] = {reinterpret_cast<const uint32_t*>(status_dev)};
+    uint32_t v = 0;
+    const int rc = pings::host_read_words(w, 1, &v, st);
+    if (rc != PINGS_OK) return rc;
+    *status_host = (int32_t)v;
+  }
   return PINGS_OK;
+}
+
+PINGS_API int pings_reg_solve(const float* normal_eq, float lm_lambda, double* T_out, double* t_out, void* stream) {
+  return pings_reg_solve_checked(normal_eq, lm_lambda, T_out, t_out, nullptr, nullptr, stream);
 }
 
 PINGS_API size_t pings_reg_normal_equations_scratch_bytes(void) { return sizeof(double) * kBlocks * kTerms; }

@@ -58,7 +58,8 @@ def shard_batch(n: int, r: int = None, w: int = None) -> slice:
 class GradBucket:
     """Gradients of `params` in one persistent flat buffer; `p.grad` are views of it.
 
-    Per step: `zero(n_backwards)` (one memset; replaces `opt.zero_grad()` for these parameters) -> `n_backwards`
+    Per step: `zero(n_backwards)` (one memset; replaces `opt.zero_grad()` for these parameters; `len(views_for_rank(..))`,
+    0 on a rank without a view) -> `n_backwards`
     forward / backward passes (autograd accumulates in place into the views; a rank that holds several views of a
     frame, `views_for_rank`, runs one backward per view) -> `finish()` before `opt.step()` (issues the collective if
     the hooks did not, waits, averages).  With `overlap=True` the all-reduce is issued asynchronously from a
@@ -96,9 +97,15 @@ class GradBucket:
 
     # -- per step
     def zero(self, n_backwards: int = 1) -> None:
-        """Clear the bucket for a step of `n_backwards` backward passes (one per view this rank renders)."""
-        if n_backwards < 1:
-            raise ValueError("GradBucket.zero: n_backwards must be >= 1")
+        """Clear the bucket for a step of `n_backwards` backward passes (one per view this rank renders).
+
+        n_backwards = 0: this rank holds no view in this step (more GPUs than cameras, `views_for_rank` empty).  Its
+        all-zero contribution is launched right here, so that every rank issues its collectives in the same order —
+        bucket first (the other ranks' hooks fire inside their backward), the row exchange after it.  Launching it
+        only in `finish()`, i.e. after the row exchange, would interleave the two collectives differently on the
+        idle rank and deadlock the group."""
+        if n_backwards < 0:
+            raise ValueError("GradBucket.zero: n_backwards must be >= 0")
         if self._work is not None:
             raise RuntimeError("GradBucket.zero() while an all-reduce is in flight: call finish() first")
         self.flat.zero_()
@@ -107,6 +114,18 @@ class GradBucket:
                 p.grad = v                      # someone ran zero_grad(set_to_none=True): re-attach the view
         self._pending = n_backwards * len(self.params)
         self._late = 0
+        if n_backwards == 0:
+            self._launch()
+
+    def skip_backward(self) -> None:
+        """An announced backward pass will not happen after all (`render` returned None: a view that sees fewer than
+        ten neural points, gaussian_renderer/__init__.py:224-292).  Launches the collective now if this was the last
+        pass the bucket waited for — same ordering argument as `zero(0)`."""
+        if world() == 1 or self._work is not None:
+            return
+        self._pending = max(self._pending - len(self.params), 0)
+        if self._pending == 0:
+            self._launch()
 
     def _on_grad(self, p: torch.Tensor) -> None:
         if world() == 1:

@@ -60,9 +60,9 @@ def _declare(L):
     L.pings_gather_rows_multi.restype = C.c_int
     L.pings_gather_rows_multi.argtypes = [C.POINTER(_GatherJob), i32, vp, vp]
     L.pings_map_prune_mask.restype = C.c_int
-    L.pings_map_prune_mask.argtypes = [i64, vp, i32, vp, vp, f32, f32, vp, vp]
+    L.pings_map_prune_mask.argtypes = [i64, vp, i64, i32, vp, vp, f32, f32, vp, vp, vp]
     L.pings_map_adjust.restype = C.c_int
-    L.pings_map_adjust.argtypes = [i64, vp, vp, vp, vp, i32, vp, i32, i64, vp]
+    L.pings_map_adjust.argtypes = [i64, vp, vp, vp, vp, i32, vp, i32, i64, vp, vp]
     L.pings_map_rehash.restype = C.c_int
     L.pings_map_rehash.argtypes = [vp, vp, i64, f32, i64, vp, vp, vp]
     L.pings_gather_rows.restype = C.c_int
@@ -370,6 +370,17 @@ def _compact_rows(m, L, rows: torch.Tensor):
         m.color_features = _gather(L, m.color_features, rows_pad, k + 1)
 
 
+def _ts_tensor(t, name, n):
+    """A per-point timestamp tensor as the kernels read it: contiguous int32 [n] on the device (the reference's dtype,
+    model/neural_gaussians.py:53-54).  Anything else — int64 timestamps from a foreign checkpoint, a stale length —
+    would be read with the wrong stride: refuse it."""
+    if t.dtype != torch.int32:
+        raise TypeError(f"{name} must be an int32 tensor (model/neural_gaussians.py:53-54), got {t.dtype}")
+    if t.dim() != 1 or int(t.shape[0]) != n:
+        raise ValueError(f"{name} must have one entry per neural point ({n}), got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
 def prune_map(m, prune_certainty_thre, min_prune_count=500) -> bool:
     """`NeuralPoints.prune_map` (model/neural_gaussians.py:871-909): drops the inactive, uncertain neural points when
     there are more than `min_prune_count` of them; the caller recreates the hash and the local map afterwards."""
@@ -378,13 +389,20 @@ def prune_map(m, prune_certainty_thre, min_prune_count=500) -> bool:
     dev = m.neural_points.device
     n = int(m.neural_points.shape[0])
     travel = m.travel_dist.detach().to(device=dev, dtype=torch.float32).contiguous()
+    ts_update = _ts_tensor(m.point_ts_update, "point_ts_update", n)
+    cur_ts, T = int(m.cur_ts), int(travel.shape[0])
+    if not -T <= cur_ts < T:            # the reference's `self.travel_dist[self.cur_ts]` raises
+        raise IndexError(f"cur_ts {cur_ts} is out of bounds for travel_dist of size {T}")
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
-    _lib.check(L.pings_map_prune_mask(n, _lib.ptr(travel), int(m.cur_ts), _lib.ptr(m.point_ts_update.contiguous()),
+    oob = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.pings_map_prune_mask(n, _lib.ptr(travel), T, cur_ts % T, _lib.ptr(ts_update),
                                       _lib.ptr(m.point_certainties.contiguous()), float(m.diff_travel_dist_local),
-                                      float(prune_certainty_thre), _lib.ptr(mask), _lib.stream_ptr(dev)),
+                                      float(prune_certainty_thre), _lib.ptr(mask), _lib.ptr(oob), _lib.stream_ptr(dev)),
                "pings_map_prune_mask")
     _lib.note_sync("prune_count")                      # reference: `.item()` at :882
-    prune_count = int(mask.sum().item())
+    prune_count, bad = torch.stack([mask.sum(dtype=torch.int64), oob[0].to(torch.int64)]).tolist()
+    if bad:                                            # `self.travel_dist[self.point_ts_update]` raises in the reference
+        raise IndexError(f"point_ts_update holds a timestamp outside travel_dist (size {T})")
     if prune_count > min_prune_count:
         if not getattr(m, "silence", True):
             print("# Prune neural points: ", prune_count)
@@ -410,9 +428,18 @@ def adjust_map(m, pose_diff_torch: torch.Tensor) -> None:
         pts, quat = pts.contiguous(), quat.to(torch.float32).contiguous()
         m.neural_points, m.point_orientations = pts, quat
     n = int(pts.shape[0])
-    _lib.check(L.pings_map_adjust(n, _lib.ptr(pts), _lib.ptr(quat), _lib.ptr(m.point_ts_create.contiguous()),
-                                  _lib.ptr(m.point_ts_update.contiguous()), int(bool(getattr(cfg, "use_mid_ts", False))),
-                                  _lib.ptr(pose), int(f64), int(pose.shape[0]), _lib.stream_ptr(dev)), "pings_map_adjust")
+    if pose.dim() != 3 or tuple(pose.shape[1:]) != (4, 4) or pose.shape[0] == 0:
+        raise ValueError(f"pose_diff_torch must be [T, 4, 4], got {tuple(pose.shape)}")
+    oob = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.pings_map_adjust(n, _lib.ptr(pts), _lib.ptr(quat), _lib.ptr(_ts_tensor(m.point_ts_create, "point_ts_create", n)),
+                                  _lib.ptr(_ts_tensor(m.point_ts_update, "point_ts_update", n)),
+                                  int(bool(getattr(cfg, "use_mid_ts", False))),
+                                  _lib.ptr(pose), int(f64), int(pose.shape[0]), _lib.ptr(oob), _lib.stream_ptr(dev)),
+               "pings_map_adjust")
+    _lib.note_sync("adjust_map_bounds")                # once per loop closure; `pose_diff_torch[used_ts]` raises in the reference
+    if int(oob.item()):
+        raise IndexError(f"a neural point's timestamp is outside pose_diff_torch (size {int(pose.shape[0])}); the points "
+                         "with valid timestamps have been moved")
     _table_changed(m)                                  # positions moved: the table and every index of it are stale
 
 
@@ -450,6 +477,8 @@ def recreate_hash(m, sensor_position: torch.Tensor, sensor_orientation: torch.Te
     _table_changed(m)
     if sensor_position is not None:
         reset_local_map(m, sensor_position, sensor_orientation, cur_ts)
+    if not kept_points and hasattr(m, "record_memory"):      # the reference's bookkeeping after a merge (:1023-1024)
+        m.record_memory(verbose=not getattr(m, "silence", True))
 
 
 def new_map(buffer_size: int, geo_dim: int, color_dim: int, resolution: float, temporal_local_map_on=True,

@@ -110,6 +110,8 @@ class _SpawnRaster(torch.autograd.Function):
         key = (nk, P, H, W)
         sizes = _BLOB_SIZES.get(key)
         if sizes is None:
+            if len(_BLOB_SIZES) > 64:      # a new (n_all * k, P) nearly every mapped frame: keep the cache small
+                _BLOB_SIZES.clear()
             sizes = _BLOB_SIZES[key] = (al(4 * max(nk, 1)), al(L.pings_spawn_plan_scratch_bytes(nk)),
                                         al(L.pings_raster_geom_bytes(P, H, W)), al(L.pings_raster_image_bytes(H, W)))
         blob = torch.empty(256 + sum(sizes), **u8)

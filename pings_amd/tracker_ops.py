@@ -25,6 +25,11 @@ from . import _lib
 from . import neural_points as _np
 
 
+REG_SINGULAR, REG_ILL_CONDITIONED, REG_NONFINITE = 1, 2, 4     # include/pings_hip.h: PINGS_REG_*
+_REG_CHECK = __import__("os").environ.get("PINGS_REG_CHECK", "1") != "0"
+last_solve_status = None    # int32[1] device tensor of the most recent `implicit_reg` (bit mask above)
+
+
 def _declare(L):
     if getattr(L, "_trk_declared", False):
         return
@@ -35,6 +40,8 @@ def _declare(L):
     L.pings_reg_normal_equations.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
     L.pings_reg_solve.restype = C.c_int
     L.pings_reg_solve.argtypes = [vp, C.c_float, vp, vp, vp]
+    L.pings_reg_solve_checked.restype = C.c_int
+    L.pings_reg_solve_checked.argtypes = [vp, C.c_float, vp, vp, vp, C.POINTER(C.c_int32), vp]
     L._trk_declared = True
 
 
@@ -64,8 +71,32 @@ def implicit_reg(points, sdf_grad, sdf_residual, weight, lm_lambda=0.0, require_
     # damping, fp64 solve and exponential map in one kernel (`pings_reg_solve`; N_mat / g_vec are views of one buffer)
     L = _lib.lib()
     T_mat = torch.empty(4, 4, dtype=torch.float64, device=points.device)
-    _lib.check(L.pings_reg_solve(N_mat.data_ptr(), float(lm_lambda), T_mat.data_ptr(), None,
-                                 _lib.stream_ptr(points.device)), "pings_reg_solve")
+    # The reference's `torch.linalg.inv` (utils/tracker.py:668) synchronises to read LAPACK's info word and raises
+    # LinAlgError on a singular N.  The kernel leaves a status word; it is read back here with one polled wait (the
+    # tracker compares the step against its thresholds on the host a few lines later anyway, :165-172), so a
+    # degenerate registration surfaces where the reference's does instead of as NaN poses.  PINGS_REG_CHECK=0 skips
+    # the wait (status stays on the device in `last_solve_status`).
+    status_dev = torch.empty(1, dtype=torch.int32, device=points.device)
+    host = C.c_int32(0)
+    checked = _REG_CHECK
+    _lib.check(L.pings_reg_solve_checked(N_mat.data_ptr(), float(lm_lambda), T_mat.data_ptr(), None,
+                                         status_dev.data_ptr(), C.byref(host) if checked else None,
+                                         _lib.stream_ptr(points.device)), "pings_reg_solve_checked")
+    global last_solve_status
+    last_solve_status = status_dev
+    if checked:
+        _lib.note_sync("reg_solve_status")
+        st = int(host.value)
+        if st & REG_SINGULAR:
+            raise torch.linalg.LinAlgError(
+                "implicit_reg: the damped normal matrix is singular (a pivot is exactly zero or not finite); "
+                "the reference's torch.linalg.inv raises here as well (utils/tracker.py:668)")
+        if st & (REG_ILL_CONDITIONED | REG_NONFINITE):
+            import warnings
+
+            warnings.warn("implicit_reg: " + ("non-finite registration step" if st & REG_NONFINITE else
+                          "normal matrix ill-conditioned (smallest pivot < 1e-7 of its largest entry)") +
+                          "; the step is returned as computed, as the reference's inverse would be", RuntimeWarning)
     eigenvalues = None
     if require_eigen:
         eigenvalues = torch.linalg.eigvals(N_mat_raw[3:, 3:]).real

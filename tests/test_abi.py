@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     missing = [n for n in _lib.header_symbols() if not hasattr(L, n)]
     assert not missing, f"symbols declared in include/pings_hip.h but not exported: {missing}"
-    assert L.pings_abi_version() >= 1
+    assert L.pings_abi_version() == _lib.expected_abi() >= 7
     assert L.pings_last_error() is not None
 
 
@@ -25,3 +25,15 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert st == 1
     assert b"null" in L.pings_last_error()
     assert L.pings_ssim_partials_count(0, 8, 8) == 0
+
+
+def test_a_library_of_another_abi_version_is_refused(monkeypatch):
+    """a stale or A/B library must not be called with this package's argtypes."""
+    import pytest
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "expected_abi", lambda: 10_000)
+    with pytest.raises(_lib.PingsHipError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().pings_abi_version() == _lib.expected_abi()

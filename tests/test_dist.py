@@ -304,3 +304,57 @@ def test_four_cameras_on_four_ranks_sparse_table_and_hooked_bucket():
             # bucket's buffer is not the one-shot call's: equal up to fp32 summation order
             assert abs(a - d).max() <= 1e-5 * max(1.0, abs(d).max())
             assert abs(a - s.numpy()).max() <= 1e-5 * max(1.0, abs(s.numpy()).max())
+
+
+# ------------------------------------------------------------------ more ranks than views
+def _worker5(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        views = pdist.views_for_rank(2)                 # two cameras, three ranks: rank 2 holds no view
+        feats, cfeats, mlp = _make_model()
+        b_mlp = pdist.GradBucket(mlp, overlap=True)
+        ex = pdist.RowSparseExchange()
+        # a rank without a view runs no backward: zero(0) launches its all-zero contribution at once, so that every rank
+        # issues bucket all-reduce -> row exchange in the same order (the other ranks' hooks fire inside backward)
+        b_mlp.zero(len(views))
+        feats.grad, cfeats.grad = torch.zeros_like(feats), torch.zeros_like(cfeats)
+        rows = torch.zeros(0, dtype=torch.int64)
+        for v in views:
+            loss, idx = _view_loss(feats, cfeats, mlp, v)
+            loss.backward()
+            rows = idx
+        tab = torch.cat([feats.grad, cfeats.grad], 1)
+        ex.reduce_(tab, rows)
+        b_mlp.finish()
+        q.put((rank, views, tab.numpy(), [p.grad.numpy() for p in mlp], dict(ex.last)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_views_idle_rank_joins_the_exchange_with_no_rows():
+    """`views_for_rank` returns nothing on some ranks (two cameras on three GPUs).  The idle rank
+    contributes zero rows and zero decoder gradients, every rank ends with the same bits, and the mean is taken over
+    the WORLD size — the reduction bench.py and INTEGRATION.md §5 state (mean over ranks)."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker5, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0], [1], []]
+    feats, cfeats, mlp = _make_model()
+    for v in range(2):
+        _view_loss(feats, cfeats, mlp, v)[0].backward()
+    seq_tab = (torch.cat([feats.grad, cfeats.grad], 1) / 3).numpy()
+    for _, _, tab, g_mlp, last in res:
+        assert last["rows_per_rank"] == [60, 60, 0] and last["mode"] == "sparse"
+        assert (tab == res[0][2]).all() and (tab == seq_tab).all()
+        for a, a0, p in zip(g_mlp, res[0][3], mlp):
+            assert (a == a0).all()
+            assert abs(a - (p.grad / 3).numpy()).max() <= 1e-5 * max(1.0, float(p.grad.abs().max()) / 3)

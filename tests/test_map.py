@@ -201,6 +201,50 @@ def test_map_hip_matches_reference_golden(golden_dir, name):
     _run_frames(_load(golden_dir, name), _HipAdapter(), "cuda")
 
 
+def test_timestamp_tensors_are_validated_before_any_kernel_reads_them():
+    """the loop-closure kernels index device memory with the map's timestamps; a tensor of another dtype
+    (int64 timestamps of a foreign checkpoint) or length is refused on the host — no GPU needed for this check."""
+    from pings_amd import neural_map as NM
+
+    ok = torch.zeros(5, dtype=torch.int32)
+    assert NM._ts_tensor(ok, "point_ts_update", 5) is not None
+    with pytest.raises(TypeError, match="int32"):
+        NM._ts_tensor(torch.zeros(5, dtype=torch.int64), "point_ts_update", 5)
+    with pytest.raises(ValueError, match="one entry per neural point"):
+        NM._ts_tensor(ok, "point_ts_update", 6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES[:1])
+def test_map_closure_hip_out_of_range_timestamps_raise(golden_dir, name):
+    """The reference's `travel_dist[point_ts_update]` / `pose_diff[used_ts]` raise IndexError on a timestamp beyond the
+    trajectory (model/neural_gaussians.py:873-876, :922-929); the kernels flag it instead of reading out of bounds."""
+    from pings_amd import neural_map as NM
+
+    st, cst = _load(golden_dir, name), _load_closure(golden_dir, name)
+    m = _run_frames(st, _HipAdapter(), "cuda")
+    m.cur_ts = int(st["frames"]) - 1
+    m.point_certainties = torch.from_numpy(cst["certainties_in"]).cuda()
+    good = m.point_ts_update.clone()
+    T = int(m.travel_dist.shape[0])
+    m.point_ts_update = good.clone()
+    m.point_ts_update[3] = T + 5
+    n0 = int(m.neural_points.shape[0])
+    with pytest.raises(IndexError):
+        NM.prune_map(m, float(cst["prune_thre"]), int(cst["min_prune_count"]))
+    assert int(m.neural_points.shape[0]) == n0          # nothing was compacted
+    m.point_ts_update = good.to(torch.int64)
+    with pytest.raises(TypeError):
+        NM.prune_map(m, float(cst["prune_thre"]), int(cst["min_prune_count"]))
+    m.point_ts_update = good
+    pose = torch.from_numpy(cst["pose_diff"]).cuda()
+    with pytest.raises(IndexError):
+        NM.adjust_map(m, pose[: max(1, int(m.point_ts_create.max().item()))])   # one pose short
+    m.cur_ts = T + 1
+    with pytest.raises(IndexError):
+        NM.prune_map(m, float(cst["prune_thre"]), int(cst["min_prune_count"]))
+
+
 @pytest.mark.gpu
 def test_map_product_path_rejects_host_tensors():
     from pings_amd import _lib, neural_map as NM

@@ -119,6 +119,80 @@ def test_mark_visible_oracle():
     assert not m[:50].any()  # the behind-camera block
 
 
+def _sublists(o_small, o_big):
+    """Every tile's list of `o_small` is a sub-sequence (order kept) of the same tile's list of `o_big`; returns the
+    (tile, Gaussian) pairs only `o_big` holds."""
+    extra = []
+    for t in range(o_big["ranges"].shape[0]):
+        a = o_small["point_list"][o_small["ranges"][t, 0]:o_small["ranges"][t, 1]]
+        b = o_big["point_list"][o_big["ranges"][t, 0]:o_big["ranges"][t, 1]]
+        keep = np.isin(b, a)
+        assert np.array_equal(b[keep], a), t
+        extra += [(t, int(g)) for g in b[~keep]]
+    return extra
+
+
+def _last_contributor(o):
+    """n_contrib (1-based position in the tile's list) -> Gaussian id of the last blended record, -1 = none."""
+    nc = np.asarray(o["n_contrib"])
+    H, W = nc.shape
+    gx = (W + 15) // 16
+    out = np.full((H, W), -1, dtype=np.int64)
+    ys, xs = np.nonzero(nc)
+    t = (ys // 16) * gx + xs // 16
+    out[ys, xs] = o["point_list"][o["ranges"][t, 0] + nc[ys, xs] - 1]
+    return out
+
+
+@pytest.mark.parametrize("mode,front_only,seed,smax", [("surfel", True, 61, 0.6), ("surfel", False, 62, 2.5),
+                                                       ("3dgs", True, 63, 0.6)])
+def test_oracle_tight_rectangle_is_lossless(mode, front_only, seed, smax):
+    """The default tile rectangle ("tight": published 3 sigma square minus the tiles no pixel of which can pass the
+    alpha >= 1/255 test) against the published square (`rect="3sigma"`, gaussian_renderer/__init__.py:318-326 ->
+    3DGS getRect): same radii, sub-lists in the same order, and every output identical — the dropped instances are
+    evaluated as alpha < 1/255 at every pixel of their tile.  smax = 2.5 m adds thin, screen-sized footprints
+    (edge-on surfels: the conic's conditioning enters the box's margin)."""
+    P, W, H = 1200, 200, 120
+    sc = make_scene(P, W, H, seed=seed, surfel=(mode == "surfel"), smax=smax)
+    sc["op"][::7] = 0.003          # peak alpha below 1/255: touches nothing, yet keeps its published radius
+    names = ["means", "col", "op", "scales", "rot"]
+    outs = {}
+    for rule in ("tight", "3sigma", "ellipse"):
+        so = oracle_settings(sc, torch.float32, mode, front_only)
+        so.rect = rule
+        outs[rule] = R.rasterize(*[sc[k].float() for k in names], so, return_debug=True)
+    ot, os_, oe = outs["tight"], outs["3sigma"], outs["ellipse"]
+    assert (ot["radii"] == os_["radii"]).all()
+    extra = _sublists(ot, os_)
+    assert 0 < len(ot["point_list"]) < len(os_["point_list"]) and len(extra) == len(os_["point_list"]) - len(ot["point_list"])
+    # the dropped pairs never pass the alpha test (the oracle's own fp32 evaluation, op order of the blend)
+    g = os_["geom"]
+    gx = (W + 15) // 16
+    for t, gi in extra:
+        ty, tx = divmod(t, gx)
+        yy, xx = torch.meshgrid(torch.arange(ty * 16, min(ty * 16 + 16, H)), torch.arange(tx * 16, min(tx * 16 + 16, W)),
+                                indexing="ij")
+        dx, dy = g["mx"][gi] - xx.float(), g["my"][gi] - yy.float()
+        power = -0.5 * (g["conic_x"][gi] * dx * dx + g["conic_z"][gi] * dy * dy) - g["conic_y"][gi] * dx * dy
+        al = sc["op"].float()[gi, 0] * torch.exp(power)
+        assert not ((power <= 0) & (al >= R.ALPHA_MIN)).any(), (t, gi)
+    # (the oracle adds a tile's records with a vectorised sum whose association depends on the list length, so its two
+    # images agree to fp32 summation order, not bit for bit; the HIP kernels blend serially and ARE bit-identical:
+    # test_default_rectangle_is_lossless)
+    for k in ("color", "depth", "alpha") + (("normal", "contributions") if mode == "surfel" else ()):
+        assert rel_err(ot[k], os_[k]) <= 2e-6, (k, rel_err(ot[k], os_[k]))
+    if mode != "surfel":
+        assert torch.equal(ot["n_touched"], os_["n_touched"])
+    assert np.array_equal(_last_contributor(ot), _last_contributor(os_))
+    # ... whereas the rounds 1-3 box truncates (kept selectable so that the difference stays measurable)
+    assert len(oe["point_list"]) < len(ot["point_list"])
+    if smax < 1.0:   # (screen-sized footprints cover every tile of the image under either rule)
+        assert (oe["color"] - os_["color"]).abs().max().item() > 1e-4
+    print(f"\n[oracle rect rules {mode}] instances: 3sigma {len(os_['point_list'])}, tight {len(ot['point_list'])}, "
+          f"ellipse {len(oe['point_list'])}; max |d colour| ellipse vs 3sigma {(oe['color'] - os_['color']).abs().max().item():.2e}")
+
+
+
 # ------------------------------------------------------------------ GPU: parity
 CASES = [("surfel", True, 21), ("surfel", False, 22), ("3dgs", True, 23)]
 
@@ -215,14 +289,17 @@ def _undecidable(o32, o64=None):
     return pix, gs
 
 
-def _oracle_grads(sc, dt, mode, front_only, seeds=5):
-    """Oracle forward + autograd backward in dtype `dt` against fixed random upstream gradients."""
-    o, leaves, theta, rho = _oracle(sc, dt, mode, front_only, grads=True)
+def _oracle_grads(sc, dt, mode, front_only, seeds=5, margins=False, tile_subset=None, pix_mask=None):
+    """Oracle forward + autograd backward in dtype `dt` against fixed random upstream gradients (zero outside
+    `pix_mask` when the oracle blends a subset of the tiles only)."""
+    o, leaves, theta, rho = _oracle(sc, dt, mode, front_only, grads=True, margins=margins, tile_subset=tile_subset)
     H, W = sc["H"], sc["W"]
     g = torch.Generator().manual_seed(seeds)
     f64 = torch.float64
     gc, gn = torch.randn(3, H, W, generator=g, dtype=f64), torch.randn(3, H, W, generator=g, dtype=f64)
     gd, ga = torch.randn(1, H, W, generator=g, dtype=f64), torch.randn(1, H, W, generator=g, dtype=f64)
+    if pix_mask is not None:
+        gc, gn, gd, ga = (t * pix_mask.to(f64) for t in (gc, gn, gd, ga))
     loss = (o["color"] * gc.to(dt)).sum() + (o["depth"] * gd.to(dt)).sum() + (o["alpha"] * ga.to(dt)).sum()
     if mode == "surfel":
         loss = loss + (o["normal"] * gn.to(dt)).sum()
@@ -293,6 +370,9 @@ def _assert_grad_gate_identified(names, got, ref64, ref32, what, g_flag):
         ef = (a2[g_flag] - r2[g_flag]).abs().max().item() / scale if g_flag.any() else 0.0
         print(f"  {name:7s} {eh:9.2e} | {eo:9.2e}     flagged rows: {ef:9.2e}")
         assert eh <= max(1e-4, 1.5 * eo), (what, name, eh, eo)
+        if g_flag.any():   # the flagged rows are not exempt either: 1e-3 in relative L2 as a set (or the fp32 oracle's own distance)
+            nf = max(r2[g_flag].norm().item(), 1e-30)
+            assert (a2[g_flag] - r2[g_flag]).norm().item() / nf <= max(1e-3, 2.0 * (o2[g_flag] - r2[g_flag]).norm().item() / nf), (what, name)
         k = max(8, int(1e-3 * a.numel()))
         assert _max_without_worst(a, b64, k) <= max(1e-4, 1.5 * _errs(b32, b64)[0]), (what, name)
 
@@ -361,6 +441,11 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
     o32, *_ = _oracle(sc, torch.float32, "surfel", True, margins=True)
     o64, names, ref64, ups = _oracle_grads(sc, torch.float64, "surfel", True)
     pix_flag, g_flag = _undecidable(o32, o64)
+    # VERDICT r3 #5 / ADVICE r3: the set the 1e-4 max-norm gate sets aside may not grow silently
+    pix_cap, g_cap = bench.UNDECIDABLE_CEILING[kind]
+    pix_frac, g_frac = float(pix_flag.float().mean()), float(g_flag.float().mean())
+    print(f"\n[{kind}] undecidable: {pix_frac:.5f} of the pixels (ceiling {pix_cap}), {g_frac:.4f} of the Gaussians (ceiling {g_cap})")
+    assert pix_frac <= pix_cap and g_frac <= g_cap, (kind, pix_frac, g_frac)
     _, _, ref32, _ = _oracle_grads(sc, torch.float32, "surfel", True)
     hr, prep, fs, radii, per_g = _hip_forward(sc, "surfel", True)
     pl, rg, fT, nc = hr.debug_lists(fs)
@@ -388,9 +473,44 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
             ref = o64[k].double()
             err = (t.detach().double().cpu() - ref).abs().amax(0) / max(ref.abs().max().item(), 1e-30)
             assert err[~pix_flag].max().item() <= 1e-4, (k, err[~pix_flag].max().item(), int(pix_flag.sum()))
+            # ... and the flagged pixels are not exempt: as a set they agree to 1e-3 in relative L2
+            if pix_flag.any():
+                dflag = (t.detach().double().cpu() - ref)[:, pix_flag]
+                assert dflag.norm().item() <= 1e-3 * max(ref[:, pix_flag].norm().item(), 1e-30), k
     print(f"  undecidable pixels: {int(pix_flag.sum())} of {pix_flag.numel()}")
     _, got, _ = _hip_grads(sc, "surfel", True, ups)
     _assert_grad_gate_identified(names, got, ref64, ref32, f"{kind} {P}@{W}x{H}", g_flag)
+
+
+@pytest.mark.gpu
+def test_c2_shape_gradients_match_the_oracle_on_a_tile_subset():
+    """an oracle-checked GRADIENT test on the C2 shape — Replica-like room at the full 640x480 with the
+    bench's intrinsics, density halved to 100k surfels so that the fp32 + fp64 autograd oracles finish in half a minute; the
+    oracle blends a checkerboard of the 1,200 tiles (`tile_subset`) and the upstream gradients are zero on the others,
+    so both sides differentiate the same loss.  Every gradient tensor under the identified-set gate, the flagged
+    fraction under the room ceiling."""
+    import bench
+    from scenes import room_scene, scene_as_dict
+
+    P, W, H, fx = 100_000, 640, 480, 600.0
+    sc = scene_as_dict(*room_scene(P, device="cpu", seed=2), W, H, fx)
+    sub = lambda tx, ty: (tx + ty) % 2 == 0
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ty_, tx_ = torch.meshgrid(torch.arange(gy), torch.arange(gx), indexing="ij")
+    in_sub = ((tx_ + ty_) % 2 == 0).repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+    o32, names, ref32, ups = _oracle_grads(sc, torch.float32, "surfel", True, margins=True, tile_subset=sub, pix_mask=in_sub)
+    o64, _, ref64, _ = _oracle_grads(sc, torch.float64, "surfel", True, tile_subset=sub, pix_mask=in_sub)
+    pix_flag, g_flag = _undecidable(o32, o64)
+    pix_cap, g_cap = bench.UNDECIDABLE_CEILING["room"]
+    pix_frac, g_frac = float(pix_flag.float().mean()), float(g_flag.float().mean())
+    print(f"\n[C2 shape {P}@{W}x{H}] undecidable: {pix_frac:.5f} of the pixels, {g_frac:.4f} of the Gaussians")
+    assert pix_frac <= pix_cap and g_frac <= g_cap
+    out, got, _ = _hip_grads(sc, "surfel", True, ups)
+    for k, t in zip(("color", "normal", "depth", "alpha"), out[:4]):
+        ref = o64[k].double()
+        err = (t.detach().double().cpu() - ref).abs().amax(0) / max(ref.abs().max().item(), 1e-30)
+        assert err[in_sub & ~pix_flag].max().item() <= 1e-4, k
+    _assert_grad_gate_identified(names, got, ref64, ref32, f"C2 shape {P}@{W}x{H}, checkerboard of tiles", g_flag)
 
 
 @pytest.mark.gpu
@@ -439,34 +559,115 @@ def test_c2_full_size_forward_matches_the_fp32_oracle():
         assert e[1] <= 1e-4, e
 
 
+def _rect_scene(kind):
+    import bench
+    from scenes import room_scene, scene_as_dict, street_scene
+
+    if kind == "random":
+        sc = make_scene(1500, 200, 120, seed=61)
+        sc["op"][::7] = 0.003      # peak alpha below 1/255: no tile, published radius
+        return sc
+    if kind == "random_thin":      # screen-sized edge-on surfels: conic conditioning up to ~1e5
+        return make_scene(1200, 200, 120, seed=62, smax=2.5)
+    if kind == "cloud":            # the bench's Metric-1 cloud, reduced
+        return scene_as_dict(*bench.synth_cloud(16000, 480, 272, 250.0, 250.0, "cpu", seed=42), 480, 272, 250.0)
+    return scene_as_dict(*street_scene(24000, device="cpu", seed=3), 348, 128, 180.0)
+
+
 @pytest.mark.gpu
-def test_tile_rectangle_variant_3sigma_square(monkeypatch):
-    """DESIGN §3 assumption 1 kept measurable: with PINGS_RASTER_RECT=3sigma the kernel emits the published 3DGS
-    tile square; its lists are bit-exact the oracle's `rect="3sigma"` lists, the default (ellipse bounding box) lists
-    are sub-lists of them, and the images of the two variants differ only by the alpha < ~0.011 tail."""
+@pytest.mark.parametrize("kernels", [("-1", "scan", ""), ("4", "pixel", "4"), ("1", "pixel", "1")])
+@pytest.mark.parametrize("kind,mode,front_only", [("random", "surfel", True), ("random_thin", "surfel", False),
+                                                   ("random", "3dgs", True), ("cloud", "surfel", True),
+                                                   ("street", "surfel", True)])
+def test_default_rectangle_is_lossless(kind, mode, front_only, kernels, monkeypatch):
+    """VERDICT r3 #1.  The default tile rectangle (published 3 sigma square of 3DGS getRect(), reached through
+    gaussian_renderer/__init__.py:318-326, minus the tiles in which no pixel can pass alpha >= 1/255) against
+    PINGS_RASTER_RECT=3sigma (the published square itself), same kernels forced on both sides: radii, every image,
+    the identity of every pixel's last contributor and EVERY gradient are bit-identical (the per-Gaussian
+    `contributions` sums to fp32 summation order, see below).
+    (`n_contrib` itself is a position in the tile's list and the lists differ, so it is compared as the Gaussian it
+    points to; the segmented forward and the four-wave split of long backward tiles cut by list position and are
+    switched off here: they regroup fp32 sums by list length.)"""
+    ppl, bwd, bwd_ppl = kernels
+    monkeypatch.setenv("PINGS_BLEND_PPL", ppl)
+    monkeypatch.setenv("PINGS_BLEND_BWD", bwd)
+    if bwd_ppl:
+        monkeypatch.setenv("PINGS_BLEND_BWD_PPL", bwd_ppl)
+    monkeypatch.setenv("PINGS_BLEND_SEG", "0")
+    monkeypatch.setenv("PINGS_BWD_LONG", "1000000000")
+    sc = _rect_scene(kind)
+    if mode != "surfel":
+        sc = dict(sc)
+        sc["scales"] = sc["scales"].clone()
+        sc["scales"][:, 2] = sc["scales"][:, 1]
+    H, W = sc["H"], sc["W"]
+    g = torch.Generator().manual_seed(5)
+    ups = (torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g),
+           torch.randn(1, H, W, generator=g))
+    res = {}
+    for rule in ("tight", "3sigma"):
+        monkeypatch.setenv("PINGS_RASTER_RECT", rule)
+        hr, prep, fs, radii, per_g = _hip_forward(sc, mode, front_only)
+        pl, rg, fT, nc = hr.debug_lists(fs)
+        o = dict(point_list=pl.cpu().numpy().astype(np.int64), ranges=rg.cpu().numpy().astype(np.int64),
+                 n_contrib=nc.cpu().numpy().astype(np.int64))
+        imgs = [fs.color.clone(), fs.depth.clone(), fs.alpha.clone(), fT.clone()]
+        if mode == "surfel":
+            imgs.append(fs.normal.clone())
+        out, grads, m2d = _hip_grads(sc, mode, front_only, ups)
+        res[rule] = dict(I=fs.I, radii=radii.clone(), per_g=per_g.clone(), imgs=imgs, last=_last_contributor(o),
+                         grads=[t.clone() for t in grads] + [m2d.grad.clone()], outs=[t.clone() for t in out])
+    t, q = res["tight"], res["3sigma"]
+    print(f"\n[rect {kind} {mode} fwd {ppl} bwd {bwd}{bwd_ppl}] instances after occlusion culling: tight {t['I']}, 3sigma square {q['I']}")
+    assert t["I"] < q["I"]
+    assert torch.equal(t["radii"], q["radii"])
+    # contributions / n_touched: per-Gaussian sums over the Gaussian's tile instances.  The integer count is exact; the
+    # float sum adds the same non-zero terms in the same order with more or fewer zeros between them, and
+    # per_gaussian_sum_kernel groups a long run into per-lane partial sums by POSITION — same terms, another
+    # association (the reference's own sum is an atomic one): equal to fp32 summation order, not bit for bit
+    if t["per_g"].dtype.is_floating_point:
+        assert rel_err(t["per_g"], q["per_g"]) <= 1e-6
+    else:
+        assert torch.equal(t["per_g"], q["per_g"])
+    for a, b in zip(t["imgs"] + t["outs"], q["imgs"] + q["outs"]):
+        if a.dim() == 1 and a.dtype.is_floating_point:      # `contributions` again, through the autograd op
+            assert rel_err(a, b) <= 1e-6
+        else:
+            assert torch.equal(a, b)
+    assert np.array_equal(t["last"], q["last"])
+    for k, (a, b) in enumerate(zip(t["grads"], q["grads"])):
+        assert torch.equal(a, b), (k, (a - b).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule", ["tight", "3sigma", "ellipse"])
+def test_tile_rectangle_rules_match_the_oracle_lists(rule, monkeypatch):
+    """Each of the three rectangle rules of preprocess_kernel (PINGS_RASTER_RECT) gives bit-exactly the oracle's radii,
+    (tile, depth, index) lists and tile ranges under the same `Settings.rect`; "ellipse" (the default of rounds 1-3)
+    truncates the alpha < ~0.011 tail and is opt-in only."""
     P, W, H = 1500, 200, 120
     sc = make_scene(P, W, H, seed=61)
+    sc["op"][::7] = 0.003
     monkeypatch.setenv("PINGS_RASTER_OCCLUSION", "0")
-    hr, prep, fs_e, radii_e, _ = _hip_forward(sc, "surfel", True)
-    col_e, alp_e, I_e = fs_e.color.clone(), fs_e.alpha.clone(), fs_e.I
-    monkeypatch.setenv("PINGS_RASTER_RECT", "3sigma")
-    hr, prep, fs_s, radii_s, _ = _hip_forward(sc, "surfel", True)
+    monkeypatch.setenv("PINGS_RASTER_RECT", rule)
+    hr, prep, fs, radii, _ = _hip_forward(sc, "surfel", True)
     so = oracle_settings(sc, torch.float32, "surfel", True)
-    so.rect = "3sigma"
+    so.rect = rule
     names = ["means", "col", "op", "scales", "rot"]
     o = R.rasterize(*[sc[k].float() for k in names], so, return_debug=True)
-    pl, rg, fT, nc = hr.debug_lists(fs_s)
-    assert (radii_s.cpu() == o["radii"]).all()
-    assert fs_s.I == len(o["point_list"]) and np.array_equal(pl.cpu().numpy(), o["point_list"])
+    pl, rg, fT, nc = hr.debug_lists(fs)
+    assert (radii.cpu() == o["radii"]).all()
+    assert fs.I == len(o["point_list"]) and np.array_equal(pl.cpu().numpy(), o["point_list"])
     assert np.array_equal(rg.cpu().numpy(), o["ranges"])
-    assert (nc.cpu() >= 0).all() and I_e < fs_s.I
-    d_col = (fs_s.color - col_e).abs().max().item()
-    d_alp = (fs_s.alpha - alp_e).abs().max().item()
-    print(f"\n[rect variants] instances ellipse {I_e} vs 3sigma square {fs_s.I}; max |d colour| {d_col:.2e}, "
-          f"max |d alpha| {d_alp:.2e}")
-    assert d_col <= 0.05 and d_alp <= 0.05            # only the truncated low-alpha tail differs
-    o64, *_ = _oracle(sc, torch.float64, "surfel", True)
-    assert rel_err(col_e, o64["color"]) <= 1e-4
+    assert (nc.cpu() == o["n_contrib"]).all()
+    so.rect = "3sigma"
+    o3 = R.rasterize(*[sc[k].float() for k in names], so)
+    d_col = (fs.color.cpu() - o3["color"]).abs().max().item()
+    print(f"\n[rect rule {rule}] instances {fs.I}; max |d colour| vs the published square (fp32 oracle) {d_col:.2e}")
+    if rule == "ellipse":
+        assert 1e-4 < d_col <= 0.05            # only the truncated low-alpha tail differs
+    else:
+        assert d_col <= 2e-6
 
 
 @pytest.mark.gpu

@@ -65,6 +65,37 @@ def test_hip_implicit_reg_matches_reference(golden_dir, tag):
 
 
 @pytest.mark.gpu
+def test_hip_implicit_reg_reports_degenerate_systems(golden_dir):
+    """utils/tracker.py:668: `torch.linalg.inv` raises LinAlgError on a singular normal matrix.  The HIP solve leaves a
+    status word that `implicit_reg` reads back with its one polled wait: singular -> the same exception class;
+    a rank-deficient system whose pivots are rounding noise -> a RuntimeWarning and the step as computed (the
+    reference inverts such a matrix silently); the well-conditioned goldens -> status 0."""
+    import warnings
+
+    from pings_amd import tracker_ops as TO
+
+    st = _reg(golden_dir)
+    g = lambda k: T(st[f"reg_a_{k}"]).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        TO.implicit_reg(g("points"), g("grad"), g("res"), g("w"), float(st["reg_a_lambda"]))
+    assert int(TO.last_solve_status.item()) == 0
+    n = 64
+    # every gradient zero: N = 0 exactly, the first pivot is 0 — the reference's inverse raises
+    with pytest.raises(torch.linalg.LinAlgError):
+        TO.implicit_reg(torch.rand(n, 3).cuda(), torch.zeros(n, 3).cuda(), torch.rand(n).cuda(), torch.ones(n, 1).cuda())
+    assert int(TO.last_solve_status.item()) & TO.REG_SINGULAR
+    # a plane seen head-on: only z translation and two rotations are observable (rank 3 of 6); gradient noise of 1e-6
+    # keeps the other three pivots off exact zero, ten orders of magnitude below the matrix scale
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.cat([torch.rand(n, 2, generator=gen) * 4 - 2, torch.zeros(n, 1)], 1).cuda()
+    grad = (torch.tensor([0.0, 0.0, 1.0]).expand(n, 3) + 1e-6 * torch.randn(n, 3, generator=gen)).contiguous().cuda()
+    with pytest.warns(RuntimeWarning, match="implicit_reg"):
+        TO.implicit_reg(pts, grad, torch.rand(n, generator=gen).cuda() * 0.01, torch.ones(n, 1).cuda())
+    assert int(TO.last_solve_status.item()) & (TO.REG_ILL_CONDITIONED | TO.REG_SINGULAR | TO.REG_NONFINITE)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["gs_f32", "pin_f8"])
 def test_hip_query_source_points_matches_reference(golden_dir, name):
     from pings_amd import tracker_ops as TO
