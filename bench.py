@@ -222,11 +222,16 @@ def cpu_baseline_raster(dev, P_sample=16000, W=480, H=272):
         return float(f"{d[~flag].max().item() / scale:.3e}")
 
     def rel_l2_flagged(a, b, flag):
-        """relative L2 error over the FLAGGED pixels alone (they are not exempt: bounded at 1e-3)"""
+        """[relative L2 error over the FLAGGED pixels alone, how many of them are off by more than 1e-4 max|ref|]: the
+        flagged set is not exempt — tests/test_raster.py lets 1 % of it (at least 4 pixels) exceed 1e-4, each by at most
+        one alpha = 1/255 contribution"""
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         if not bool(flag.any()):
-            return 0.0
-        return float(f"{((a - b)[:, flag].norm() / max(b[:, flag].norm().item(), 1e-30)).item():.3e}")
+            return [0.0, 0]
+        d = (a - b)[:, flag]
+        scale = max(b.abs().max().item(), 1e-30)
+        return [float(f"{(d.norm() / max(b[:, flag].norm().item(), 1e-30)).item():.3e}"),
+                int((d.abs().amax(0) > 1e-4 * scale).sum())]
 
     # VERDICT r3 #5: the undecidable set must not grow silently.  Ceilings for THIS scene (the cloud's thin footprints
     # put a rounding bound above 2e-5 on ~28 % of the pixels; tests/test_raster.py holds the street / room ceilings)

@@ -705,6 +705,19 @@ PINGS_API int pings_image_losses_backward(const pings_image_loss_params* p, cons
                                           float* dL_ddepth, float* dL_dalpha, float* dL_dnormal,
                                           float* dL_ddepth_normal, void* stream);
 
+/* ------------------------------------------------------ colour / semantic heads of a kNN query
+ * `Mesher.query_points` (utils/mesher.py:132-153) and the tracker's colour query (utils/tracker.py:322-331) apply an
+ * activation to every neighbour's decoder output raw[B, k, C] and sum over the k neighbours with the IDW weights
+ * weight[B, k] (NULL = `weighted_first`: k = 1, weight one):
+ *   PINGS_HEAD_COLOR     out_value[B, C] = sum_j w_j sigmoid(raw_j)              (Decoder.regress_color, decoder.py:133-134)
+ *   PINGS_HEAD_SEMANTIC  out_label[B] = argmax_c sum_j w_j log_softmax(raw_j)[c], first maximum as torch.argmax
+ *                        (Decoder.sem_label_prob, decoder.py:119-122); out_value (nullable) receives the [B, C] sums
+ * k <= 16.  One streaming pass instead of three to five torch passes per head. */
+#define PINGS_HEAD_COLOR 0
+#define PINGS_HEAD_SEMANTIC 1
+PINGS_API int pings_head_reduce(const float* raw, const float* weight, int64_t B, int32_t k, int32_t C, int32_t mode,
+                                float* out_value, int64_t* out_label, void* stream);
+
 /* ------------------------------------------------------ tracker registration
  * Replaces the Jacobian assembly of `implicit_reg` (utils/tracker.py:608-689): with J_i = [p_i x g_i, g_i] (rotation
  * first, then translation),  N = sum_i w_i J_i^T J_i  (6x6)  and  g = -sum_i w_i r_i J_i  (6).

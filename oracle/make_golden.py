@@ -584,8 +584,47 @@ def make_mesher(R):
     np.savez_compressed(OUT / "mesher_grid.npz", **out)
 
 
+def make_mesher_heads(R):
+    """G11b: the colour and semantic heads of `Mesher.query_points` (utils/mesher.py:132-153) on the grids of G11:
+    `color_mlp.regress_color` (sigmoid) and `sem_mlp.sem_label_prob` (log-softmax) per neighbour, IDW-weighted sum,
+    arg-max label — the reference's own Mesher and Decoder on CPU.  The two decoders' weights travel in the fixture."""
+    import types
+    from unittest.mock import MagicMock
+
+    for m in ("skimage", "skimage.measure"):
+        sys.modules.setdefault(m, MagicMock())
+    import utils.mesher as M  # type: ignore
+
+    grid = np.load(OUT / "mesher_grid.npz")
+    out = {}
+    for name in ("gs_f32", "pin_f8"):
+        kw = SDF_CASES[name]
+        cfg, npm = build_reference_map(R, kw, seed=len(name), after_pgo=False)
+        cfg.color_channel, cfg.sem_class_count = 3, 20
+        g2 = torch.Generator().manual_seed(1234)
+        col = R.Decoder(cfg, cfg.color_feature_dim, cfg.geo_mlp_hidden_dim, cfg.geo_mlp_level, cfg.color_channel)
+        sem = R.Decoder(cfg, cfg.feature_dim, cfg.sem_mlp_hidden_dim, cfg.sem_mlp_level, cfg.sem_class_count + 1)
+        with torch.no_grad():
+            for d in (col, sem):
+                for p_ in d.parameters():
+                    p_.copy_(torch.randn(p_.shape, generator=g2) * 0.4)
+        fake = types.SimpleNamespace(neural_points=npm, sdf_mlp=None, sem_mlp=sem, color_mlp=col, config=cfg,
+                                     device="cpu", cur_device="cpu", dtype=torch.float32)
+        coord = torch.from_numpy(grid[f"{name}_coord"])
+        _, sem_pred, col_pred, mask = M.Mesher.query_points(fake, coord, 500, False, True, True, True, query_locally=False,
+                                                            mask_min_nn_count=4)
+        assert np.array_equal(mask, grid[f"{name}_mask"])
+        out.update({f"{name}_sem": sem_pred, f"{name}_color": col_pred})
+        for tag, d in (("col", col), ("sem", sem)):
+            for k_, v_ in d.state_dict().items():
+                out[f"{name}_{tag}.{k_}"] = _np(v_)
+        print(f"mesher heads {name}: labels used {np.unique(sem_pred).size}, colour range "
+              f"[{col_pred.min():.3f}, {col_pred.max():.3f}], rows without neighbours {(col_pred.sum(1) == 0).sum()}")
+    np.savez_compressed(OUT / "mesher_heads.npz", **out)
+
+
 GROUPS = {"ssim": make_ssim, "sdf": make_sdf, "spawn": make_spawn, "camera": make_camera, "map": make_map,
-          "tracker": make_tracker, "imgloss": make_imgloss, "mesher": make_mesher, "mapclosure": make_map_closure}
+          "tracker": make_tracker, "imgloss": make_imgloss, "mesher": make_mesher, "mapclosure": make_map_closure, "mesher_heads": make_mesher_heads}
 
 
 def main(argv):

@@ -568,14 +568,27 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
 // are added across the four waves in LDS (wave order) and written as one partial per workgroup, summed by
 // mlp_reduce_kernel in fixed order: bitwise reproducible.
 constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
+
+// Round 4: the same five products, re-issued so that the matrix pipe does not wait for operands.
+//  * A PMC pass of round 3 put the pipe at 57 % busy; the ISA showed why: every LDS operand was fetched just in time
+//    (ds_read -> s_waitcnt -> two MFMAs), so each pair of MFMAs (128 cycles) exposed an LDS round trip, and the
+//    bounds-checked row / column loads of a tile compiled to ~100 basic blocks (one branch per load) that nothing
+//    could be scheduled across.  Now the A operands of a product are read from LDS into registers ONE PRODUCT AHEAD
+//    (while the previous product's MFMAs execute; `sched_barrier`s keep the compiler from sinking the reads back to
+//    their uses), and every global load is unconditional on a clamped address with a select afterwards.
+//  * OH = k-steps of product B (gH^T = W2^T gY^T) per lane half: OUT / 2 when the decoder's output count is one of the
+//    shipped classes (8, 24, 32: alpha; xyz / scale / colour; rotation — gaussian_renderer/__init__.py:609-708), so
+//    that product does not multiply the zero padding of a 32-wide output tile; 16 with zero padding otherwise.
+template <int OH, bool VECX, bool VECG>
 __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, const float* __restrict__ x,
                                                   const float* __restrict__ gy, const float* __restrict__ W1,
                                                   const float* __restrict__ b1, const float* __restrict__ W2,
                                                   float* __restrict__ gx, float* __restrict__ partials,
-                                                  size_t per_block) {
-  __shared__ float sW1[128 * BW_LD];        // W1[hid][i], zero beyond IN
-  __shared__ float sW2[32 * 129];           // W2[o][hid], zero beyond OUT
-  __shared__ float sT[4][2][32 * BW_LD];    // per wave: H^T and gH^T as [hid_local][row]
+                                                  size_t per_block, float* __restrict__ sW1, float* __restrict__ sW2,
+                                                  float* __restrict__ sT, float* __restrict__ sXG) {
+  // LDS (declared once in mlp_bwd_wave_dispatch): sW1 = W1[hid][i] as [128][BW_LD], zero beyond IN; sW2 = W2[o][hid] as
+  // [32][129], zero beyond OUT; sT = per wave H^T and gH^T as [4][2][32 * BW_LD] ([hid_local][row]); sXG = per wave the
+  // double-buffered x and gY tiles [4][x0, x1, g0, g1][32 * BW_LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   for (int e = tid; e < 128 * 32; e += 256) {
@@ -598,89 +611,148 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
 #pragma unroll
     for (int q = 0; q < 16; ++q) { aW2T[hb][q] = 0.f; aW1[hb][q] = 0.f; }
 
-  float* myH = &sT[wave][0][0];
-  float* myG = &sT[wave][1][0];
-  const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+  float* myH = sT + (wave * 2 + 0) * 32 * BW_LD;
+  float* myG = sT + (wave * 2 + 1) * 32 * BW_LD;
+  // the wave's private, double-buffered images of its tile of x and gY, [row][column] with leading dimension BW_LD
+  // (conflict-free by rows and by columns): the row view (B operands of products A / B) and the column view (B operands
+  // of the weight-gradient products) are both read from here, so a tile's rows are fetched from HBM ONCE, coalesced
+  // (round 3 fetched the column view with 32 more scattered, individually guarded loads per tile)
+  float* myX = sXG + (wave * 4 + 0) * 32 * BW_LD;   // + buf * 32 * BW_LD
+  float* myGY = sXG + (wave * 4 + 2) * 32 * BW_LD;
+  // lane half h of product B takes outputs o0 .. o0 + OH - 1
+  const int o0 = h * OH;
+  // every LDS access below is ONE per-lane base plus a compile-time offset (the instruction's immediate field): written
+  // as (r, h)-dependent index expressions the compiler hoisted ~100 loop-invariant addresses out of the tile loop
+  // and spilled them
+  const float* const baseA = sW1 + r * BW_LD + 16 * h;        // + hb * 32 * BW_LD + s          (A operands of product A)
+  const float* const baseB = sW2 + o0 * 129 + r;              // + s * 129 + hb * 32            (A operands of product B)
+  const float* const baseC = sW1 + 4 * h * BW_LD + r;         // + (hb * 32 + rm(q)) * BW_LD    (A operands of product C)
+  float* const wrH = myH + 4 * h * BW_LD + r;                 // + rm(q) * BW_LD                (transpose: write)
+  float* const wrG = myG + 4 * h * BW_LD + r;
+  const float* const rdH = myH + r * BW_LD + 16 * h;          // + s                            (transpose: read)
+  const float* const rdG = myG + r * BW_LD + 16 * h;
   const long long ntiles = (N + 31) / 32;
   const long long nwaves = (long long)gridDim.x * 4;
   const long long wave0 = (long long)blockIdx.x * 4 + wave;
 
-  float xn[16], gn[16];
+  // Row r of tile t: columns 16 h .. 16 h + 15 of x and of gY (zero beyond IN / OUT and beyond row N).  Every load is
+  // issued whatever the row / column — the address is clamped into the array and the value masked afterwards with
+  // integer ops — so a tile's fetch is ONE basic block with all loads in flight together.
+  // fetch_rows only LOADS (raw values stay in flight in xd / gd for the whole tile); stage_rows masks them (integer and:
+  // no select the compiler could turn back into a branch) and writes the LDS image.
   auto fetch_rows = [&](long long t, float (&xd)[16], float (&gd)[16]) {
     const long long row = t * 32 + r;
-    const bool ok = row < N;
+    const long long rowc = row < N ? row : N - 1;
+    const float* xr = x + (size_t)rowc * IN;
+    const float* gr = gy + (size_t)rowc * OUT;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int k = 16 * h + 4 * q4;
-      if (vecx) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && k < IN) v = *reinterpret_cast<const float4*>(x + (size_t)row * IN + k);
+      if (VECX) {    // IN a multiple of four, 16-byte aligned rows
+        const float4 v = *reinterpret_cast<const float4*>(xr + (k < IN ? k : 0));
         xd[4 * q4] = v.x; xd[4 * q4 + 1] = v.y; xd[4 * q4 + 2] = v.z; xd[4 * q4 + 3] = v.w;
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = (ok && k + u < IN) ? x[(size_t)row * IN + k + u] : 0.f;
+        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = xr[k + u < IN ? k + u : 0];
       }
-      if (vecg) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && k < OUT) v = *reinterpret_cast<const float4*>(gy + (size_t)row * OUT + k);
-        gd[4 * q4] = v.x; gd[4 * q4 + 1] = v.y; gd[4 * q4 + 2] = v.z; gd[4 * q4 + 3] = v.w;
+      if (VECG) {
+        const float4 u4 = *reinterpret_cast<const float4*>(gr + (k < OUT ? k : 0));
+        gd[4 * q4] = u4.x; gd[4 * q4 + 1] = u4.y; gd[4 * q4 + 2] = u4.z; gd[4 * q4 + 3] = u4.w;
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = (ok && k + u < OUT) ? gy[(size_t)row * OUT + k + u] : 0.f;
+        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = gr[k + u < OUT ? k + u : 0];
       }
     }
   };
-  if (wave0 < ntiles) fetch_rows(wave0, xn, gn);
-  for (long long t = wave0; t < ntiles; t += nwaves) {
-    float xf[16], gyf[16], xcol[16], gycol[16];
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) { xf[s2] = xn[s2]; gyf[s2] = gn[s2]; }
-    // column-wise views for the weight-gradient products: element [row = 16 h + s][column = r]
+  auto stage_rows = [&](int buf, long long t, const float (&xd)[16], const float (&gd)[16]) {
+    const uint32_t live = (t * 32 + r) < N ? 0xFFFFFFFFu : 0u;
+    float* dx = myX + buf * 32 * BW_LD + r * BW_LD + 16 * h;
+    float* dg = myGY + buf * 32 * BW_LD + r * BW_LD + 16 * h;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
-      const long long row = t * 32 + 16 * h + s2;
-      xcol[s2] = (row < N && r < IN) ? x[(size_t)row * IN + r] : 0.f;
-      gycol[s2] = (row < N && r < OUT) ? gy[(size_t)row * OUT + r] : 0.f;
+      const int c = 16 * h + s2;
+      dx[s2] = __uint_as_float(__float_as_uint(xd[s2]) & (c < IN ? live : 0u));
+      dg[s2] = __uint_as_float(__float_as_uint(gd[s2]) & (c < OUT ? live : 0u));
     }
-    // unconditional (rows beyond N load nothing): behind a branch the loads' count is unknown to the compiler and the
-    // first use of the column views waits for vmcnt(0), i.e. for this prefetch too
+  };
+  // A operands of products A (+ bias step) and B of hidden block hb, from the LDS weight images
+  float opA[17], opB[OH];
+  auto load_AB = [&](int hb) {
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) opA[s2] = baseA[hb * 32 * BW_LD + s2];
+    opA[16] = b1f[hb];
+#pragma unroll
+    for (int s2 = 0; s2 < OH; ++s2) opB[s2] = baseB[s2 * 129 + hb * 32];
+  };
+
+  float xn[16], gn[16];
+  int buf = 0;
+  fetch_rows(wave0 < ntiles ? wave0 : 0, xn, gn);
+  stage_rows(0, wave0 < ntiles ? wave0 : 0, xn, gn);
+  load_AB(0);
+  const float one = h == 0 ? 1.f : 0.f;
+  for (long long t = wave0; t < ntiles; t += nwaves) {
+    // the next tile's rows: in flight for the whole of this tile, staged into the other LDS buffer at its end
+    // (beyond the last tile the clamped addresses re-read row N - 1 and the values are never used)
     fetch_rows(t + nwaves, xn, gn);
+    __builtin_amdgcn_wave_barrier();
+    float xf[16], gyf[OH], xcol[16], gycol[16];
+    {
+      const float* bxr = myX + buf * 32 * BW_LD + r * BW_LD + 16 * h;     // row view
+      const float* bxc = myX + buf * 32 * BW_LD + 16 * h * BW_LD + r;     // column view
+      const float* bgr = myGY + buf * 32 * BW_LD + r * BW_LD + o0;
+      const float* bgc = myGY + buf * 32 * BW_LD + 16 * h * BW_LD + r;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        xf[s2] = bxr[s2];
+        xcol[s2] = bxc[s2 * BW_LD];
+        gycol[s2] = bgc[s2 * BW_LD];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < OH; ++s2) gyf[s2] = bgr[s2];
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) aB2 += gycol[s2];
-    const float one = h == 0 ? 1.f : 0.f;
     f32x16 gxacc = {0};
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
+      // ---- products A and B on the operands read one product ago; meanwhile the A operands of product C
+      float opC[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) opC[q] = baseC[(hb * 32 + (q & 3) + 8 * (q >> 2)) * BW_LD];
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 pre = {0}, gH = {0};
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) pre = mfma(sW1[(hb * 32 + r) * BW_LD + 16 * h + s2], xf[s2], pre);
-      pre = mfma(b1f[hb], one, pre);
-#pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) gH = mfma(sW2[(16 * h + s2) * 129 + hb * 32 + r], gyf[s2], gH);
+      for (int s2 = 0; s2 < 17; ++s2) {
+        pre = mfma(opA[s2], s2 < 16 ? xf[s2] : one, pre);
+        if (s2 < OH) gH = mfma(opB[s2], gyf[s2], gH);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         gH[q] = pre[q] > 0.f ? gH[q] : 0.f;
         pre[q] = fmaxf(pre[q], 0.f);
       }
-      if (gx) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) gxacc = mfma(sW1[(hb * 32 + rowmap(q, h)) * BW_LD + r], gH[q], gxacc);
-      }
-      // transpose through the wave's private LDS: [hid_local][row]
+      // ---- product C; meanwhile H^T and gH^T take their trip through the wave's private LDS ([hid_local][row])
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        myH[rowmap(q, h) * BW_LD + r] = pre[q];
-        myG[rowmap(q, h) * BW_LD + r] = gH[q];
+        wrH[((q & 3) + 8 * (q >> 2)) * BW_LD] = pre[q];
+        wrG[((q & 3) + 8 * (q >> 2)) * BW_LD] = gH[q];
       }
       __builtin_amdgcn_wave_barrier();
       float aH[16], aG[16];
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
-        aH[s2] = myH[r * BW_LD + 16 * h + s2];
-        aG[s2] = myG[r * BW_LD + 16 * h + s2];
+        aH[s2] = rdH[s2];
+        aG[s2] = rdG[s2];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gxacc = mfma(opC[q], gH[q], gxacc);   // (computed even when gx is null: no branch)
+      // ---- the weight-gradient products; meanwhile the operands of the next hidden block's A and B
+      load_AB((hb + 1) & 3);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
         aB1[hb] += aG[s2];
@@ -688,6 +760,8 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         aW1[hb] = mfma(aG[s2], xcol[s2], aW1[hb]);
       }
     }
+    stage_rows(buf ^ 1, t + nwaves, xn, gn);
+    buf ^= 1;
     if (gx) {
       const long long row = t * 32 + r;
       if (row < N) {
@@ -713,7 +787,7 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
 
   // ---- the workgroup's partial weight gradients: the four waves add theirs in wave order into the (now dead)
   // weight images, which already have the conflict-free layouts [hid][33] and [o][129]; one partial per workgroup
-  float* sB = &sT[0][0][0];  // gb1[128], gb2[32]
+  float* sB = sT;  // gb1[128], gb2[32]
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
     if (wave == w) {
@@ -743,18 +817,46 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
   if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sB[128 + tid];
 }
 
+// one instantiation per output class (the B product's k-steps are compile-time); the choice is uniform per workgroup
+__device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                      const float* __restrict__ gy, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const float* __restrict__ W2,
+                                                      float* __restrict__ gx, float* __restrict__ partials,
+                                                      size_t per_block) {
+  __shared__ float sW1[128 * BW_LD];
+  __shared__ float sW2[32 * 129];
+  __shared__ float sT[4 * 2 * 32 * BW_LD];
+  __shared__ float sXG[4 * 4 * 32 * BW_LD];     // 135 KB in all: one workgroup per CU, as the registers dictate anyway
+  // 16-byte row loads where the row length and the base allow (the colour decoder's 19 inputs: scalar loads of x)
+  const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+#define PINGS_BWD_BODY(OH_, VX_, VG_) \
+  mlp_bwd_wave_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block, sW1, sW2, sT, sXG)
+#define PINGS_BWD_CLASS(VX_)                          \
+  do {                                                \
+    if (!vecg) PINGS_BWD_BODY(16, VX_, false);        \
+    else if (OUT == 24) PINGS_BWD_BODY(12, VX_, true); \
+    else if (OUT == 8) PINGS_BWD_BODY(4, VX_, true);  \
+    else PINGS_BWD_BODY(16, VX_, true);               \
+  } while (0)
+  if (vecx) PINGS_BWD_CLASS(true);
+  else PINGS_BWD_CLASS(false);
+#undef PINGS_BWD_CLASS
+#undef PINGS_BWD_BODY
+}
+
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
                                                               const float* __restrict__ gy, const float* __restrict__ W1,
                                                               const float* __restrict__ b1, const float* __restrict__ W2,
                                                               float* __restrict__ gx, float* __restrict__ partials,
                                                               size_t per_block) {
-  mlp_bwd_wave_body(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block);
+  mlp_bwd_wave_dispatch(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block);
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_grouped_kernel(long long N, MlpJobs j) {
   const int g = blockIdx.y;
-  mlp_bwd_wave_body(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
-                    j.per_block[g]);
+  mlp_bwd_wave_dispatch(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
+                        j.per_block[g]);
 }
 
 // ---------------------------------------------------------------- backward of the SDF decoder shape: HID = 64, OUT = 1

@@ -61,6 +61,9 @@ def mlp(decoder, features: torch.Tensor) -> torch.Tensor:
         return y.view(*features.shape[:-1], y.shape[-1])
     orig = getattr(type(decoder), "_pings_mlp_torch", None)     # set by install(): the class's own method
     if orig is None:
+        cls_mlp = getattr(type(decoder), "mlp", None)           # not installed: the class's `mlp` is still its own
+        if cls_mlp is not None and cls_mlp is not mlp:
+            return cls_mlp(decoder, features)
         raise NotImplementedError("decoder.mlp: this decoder shape has no fused kernel and the class's own `mlp` was "
                                   "not kept (call pings_amd.decoder.install(Decoder))")
     return orig(decoder, features)

@@ -55,6 +55,44 @@ def test_hip_query_points_matches_reference(golden_dir, name, out_torch):
     assert np.abs(sdf - ref[f"{name}_sdf"]).max() <= 1e-4 * np.abs(ref[f"{name}_sdf"]).max()
 
 
+class _HeadDec:
+    """Duck-typed `Decoder` of a colour / semantic head from the G11b fixture."""
+
+    def __init__(self, ref, prefix):
+        t = lambda k: T(ref[f"{prefix}.{k}"]).cuda()
+        self.layers = [NS(weight=t("layers.0.weight"), bias=t("layers.0.bias"))]
+        self.lout = NS(weight=t("lout.weight"), bias=t("lout.bias"))
+        self.use_leaky_relu = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_colour_and_semantic_heads_match_reference(golden_dir, name):
+    """the colour and semantic heads of `Mesher.query_points` (utils/mesher.py:132-153) with no torch
+    tail — HIP `query_feature`, the heads' decoders on the fused MFMA kernels, one `pings_head_reduce` pass — against
+    the reference's own Mesher + Decoder (G11b, oracle/make_golden.py:make_mesher_heads): colours to 1e-5, labels equal
+    wherever the two best classes are further apart than fp32 can blur."""
+    from pings_amd import mesher_ops as MO
+
+    st, grid = load(golden_dir, name), _grid(golden_dir)
+    z = np.load(golden_dir / "mesher_heads.npz")
+    ref = {k: z[k] for k in z.files}
+    fake = NS(neural_points=_gpu_map(st), sdf_mlp=_Dec(st), sem_mlp=_HeadDec(ref, f"{name}_sem"),
+              color_mlp=_HeadDec(ref, f"{name}_col"),
+              config=NS(weighted_first=bool(st["weighted_first"]), color_channel=3))
+    coord = T(grid[f"{name}_coord"]).cuda()
+    sdf, sem, col, mask = MO.query_points(fake, coord, 1000, False, True, True, True, query_locally=False,
+                                          mask_min_nn_count=4)
+    assert sdf is None and sem.dtype == np.float64 and col.dtype == np.float64 and col.shape == (coord.shape[0], 3)
+    assert np.array_equal(mask, grid[f"{name}_mask"])
+    assert np.abs(col - ref[f"{name}_color"]).max() <= 1e-5
+    if not bool(st["weighted_first"]):
+        empty = ref[f"{name}_color"].sum(1) == 0.0
+        assert empty.sum() > 100 and np.all(col[empty] == 0.0)             # no neighbour: weights 0, colour exactly 0
+    agree = sem == ref[f"{name}_sem"]
+    assert agree.mean() >= 0.999, agree.mean()
+
+
 def test_mesher_product_path_rejects_host_tensors():
     from pings_amd import _lib, mesher_ops as MO
 

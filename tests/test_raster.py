@@ -370,9 +370,9 @@ def _assert_grad_gate_identified(names, got, ref64, ref32, what, g_flag):
         ef = (a2[g_flag] - r2[g_flag]).abs().max().item() / scale if g_flag.any() else 0.0
         print(f"  {name:7s} {eh:9.2e} | {eo:9.2e}     flagged rows: {ef:9.2e}")
         assert eh <= max(1e-4, 1.5 * eo), (what, name, eh, eo)
-        if g_flag.any():   # the flagged rows are not exempt either: 1e-3 in relative L2 as a set (or the fp32 oracle's own distance)
-            nf = max(r2[g_flag].norm().item(), 1e-30)
-            assert (a2[g_flag] - r2[g_flag]).norm().item() / nf <= max(1e-3, 2.0 * (o2[g_flag] - r2[g_flag]).norm().item() / nf), (what, name)
+        if g_flag.any():   # the flagged rows are not exempt either: all but 1 % of them (at least 8) meet the plain gate
+            bad = ((a2[g_flag] - r2[g_flag]).abs().amax(1) / scale) > max(1e-4, 1.5 * eo)
+            assert int(bad.sum()) <= max(8, int(0.01 * int(g_flag.sum()))), (what, name, int(bad.sum()), int(g_flag.sum()))
         k = max(8, int(1e-3 * a.numel()))
         assert _max_without_worst(a, b64, k) <= max(1e-4, 1.5 * _errs(b32, b64)[0]), (what, name)
 
@@ -473,10 +473,12 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
             ref = o64[k].double()
             err = (t.detach().double().cpu() - ref).abs().amax(0) / max(ref.abs().max().item(), 1e-30)
             assert err[~pix_flag].max().item() <= 1e-4, (k, err[~pix_flag].max().item(), int(pix_flag.sum()))
-            # ... and the flagged pixels are not exempt: as a set they agree to 1e-3 in relative L2
+            # ... and the flagged pixels are not exempt: a flip is one alpha ~ 1/255 contribution in ONE pixel, so all but
+            # a handful of them (4, or 1 % of the flagged set) must still be within 1e-4, and each within one flip
             if pix_flag.any():
-                dflag = (t.detach().double().cpu() - ref)[:, pix_flag]
-                assert dflag.norm().item() <= 1e-3 * max(ref[:, pix_flag].norm().item(), 1e-30), k
+                ef = err[pix_flag]
+                assert int((ef > 1e-4).sum()) <= max(4, int(0.01 * ef.numel())), (k, int((ef > 1e-4).sum()), ef.numel())
+                assert ef.max().item() <= (1e-2 if k == "depth" else 1.1 / 255), (k, ef.max().item())
     print(f"  undecidable pixels: {int(pix_flag.sum())} of {pix_flag.numel()}")
     _, got, _ = _hip_grads(sc, "surfel", True, ups)
     _assert_grad_gate_identified(names, got, ref64, ref32, f"{kind} {P}@{W}x{H}", g_flag)
@@ -507,9 +509,17 @@ def test_c2_shape_gradients_match_the_oracle_on_a_tile_subset():
     assert pix_frac <= pix_cap and g_frac <= g_cap
     out, got, _ = _hip_grads(sc, "surfel", True, ups)
     for k, t in zip(("color", "normal", "depth", "alpha"), out[:4]):
-        ref = o64[k].double()
-        err = (t.detach().double().cpu() - ref).abs().amax(0) / max(ref.abs().max().item(), 1e-30)
-        assert err[in_sub & ~pix_flag].max().item() <= 1e-4, k
+        # against the fp32 oracle (same discrete decisions): 1e-4 on every decidable pixel of the blended tiles, as the
+        # full-size forward test below; against the fp64 oracle: 1e-4 in relative L2, a handful of threshold flips
+        # (counted, each at most one alpha = 1/255 contribution), as test_mid_size_scene_* above
+        tm = t.detach().double().cpu() * in_sub
+        r32, r64 = o32[k].double(), o64[k].double()
+        err = (tm - r32).abs().amax(0) / max(r32.abs().max().item(), 1e-30)
+        assert err[in_sub & ~pix_flag].max().item() <= 1e-4, (k, err[in_sub & ~pix_flag].max().item())
+        e64 = _errs(tm, r64)
+        print(f"  {k:7s} vs fp64 oracle: max-norm {e64[0]:.2e}, rel-L2 {e64[1]:.2e}, entries > 1e-4: {e64[2]}")
+        assert e64[1] <= 1e-4 and e64[2] <= max(16, 5e-5 * tm.numel()), (k, e64)
+        assert e64[0] <= (1e-2 if k == "depth" else 1.1 / 255), (k, e64)
     _assert_grad_gate_identified(names, got, ref64, ref32, f"C2 shape {P}@{W}x{H}, checkerboard of tiles", g_flag)
 
 
