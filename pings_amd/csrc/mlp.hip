@@ -568,6 +568,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
 // are added across the four waves in LDS (wave order) and written as one partial per workgroup, summed by
 // mlp_reduce_kernel in fixed order: bitwise reproducible.
 constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
+#ifdef PINGS_MLP_STATS
+__device__ unsigned long long g_mlp_stats[8];
+#endif
 
 // Round 4: the same five products, re-issued so that the matrix pipe does not wait for operands.
 //  * A PMC pass of round 3 put the pipe at 57 % busy; the ISA showed why: every LDS operand was fetched just in time
@@ -685,12 +688,20 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
     for (int s2 = 0; s2 < OH; ++s2) opB[s2] = baseB[s2 * 129 + hb * 32];
   };
 
+#ifdef PINGS_MLP_STATS   // diagnostic build only (tools/build_stats_lib.sh): shader-clock ticks per phase of the tile loop
+  unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MLP_TICK(k_) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_t[k_] += now_ - st_last; st_last = now_; } while (0)
+  unsigned long long st_last = __builtin_readcyclecounter();
+#else
+#define MLP_TICK(k_) do { } while (0)
+#endif
   float xn[16], gn[16];
   int buf = 0;
   fetch_rows(wave0 < ntiles ? wave0 : 0, xn, gn);
   stage_rows(0, wave0 < ntiles ? wave0 : 0, xn, gn);
   load_AB(0);
   const float one = h == 0 ? 1.f : 0.f;
+  MLP_TICK(0);   // prologue
   for (long long t = wave0; t < ntiles; t += nwaves) {
     // the next tile's rows: in flight for the whole of this tile, staged into the other LDS buffer at its end
     // (beyond the last tile the clamped addresses re-read row N - 1 and the values are never used)
@@ -714,6 +725,7 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) aB2 += gycol[s2];
     f32x16 gxacc = {0};
+    MLP_TICK(1);   // tile start: operand views from LDS
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
       // ---- products A and B on the operands read one product ago; meanwhile the A operands of product C
@@ -728,11 +740,13 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         if (s2 < OH) gH = mfma(opB[s2], gyf[s2], gH);
       }
       __builtin_amdgcn_sched_barrier(0);
+      MLP_TICK(2);   // products A / B issued
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         gH[q] = pre[q] > 0.f ? gH[q] : 0.f;
         pre[q] = fmaxf(pre[q], 0.f);
       }
+      MLP_TICK(3);   // mask (waits for the products)
       // ---- product C; meanwhile H^T and gH^T take their trip through the wave's private LDS ([hid_local][row])
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -750,6 +764,7 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 16; ++q) gxacc = mfma(opC[q], gH[q], gxacc);   // (computed even when gx is null: no branch)
+      MLP_TICK(4);   // transposes + product C issued
       // ---- the weight-gradient products; meanwhile the operands of the next hidden block's A and B
       load_AB((hb + 1) & 3);
       __builtin_amdgcn_sched_barrier(0);
@@ -759,9 +774,11 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         aW2T[hb] = mfma(aH[s2], gycol[s2], aW2T[hb]);
         aW1[hb] = mfma(aG[s2], xcol[s2], aW1[hb]);
       }
+      MLP_TICK(5);   // products D issued
     }
     stage_rows(buf ^ 1, t + nwaves, xn, gn);
     buf ^= 1;
+    MLP_TICK(6);   // next tile staged
     if (gx) {
       const long long row = t * 32 + r;
       if (row < N) {
@@ -785,6 +802,11 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
     }
   }
 
+  MLP_TICK(7);   // gX store of the last tile
+#ifdef PINGS_MLP_STATS
+  if (lane == 0)
+    for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_mlp_stats[k_], st_t[k_]);
+#endif
   // ---- the workgroup's partial weight gradients: the four waves add theirs in wave order into the (now dead)
   // weight images, which already have the conflict-free layouts [hid][33] and [o][129]; one partial per workgroup
   float* sB = sT;  // gb1[128], gb2[32]
@@ -1246,6 +1268,18 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
+
+#ifdef PINGS_MLP_STATS
+PINGS_API int pings_debug_mlp_stats(unsigned long long* out8, int reset) {
+  PINGS_HIP_CHECK(hipDeviceSynchronize());
+  PINGS_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_stats), 64));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PINGS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stats), z, 64));
+  }
+  return PINGS_OK;
+}
+#endif
 
 // ---------------------------------------------------------------- grouped launches (several decoders, same rows)
 namespace {

@@ -14,6 +14,8 @@
 // HBM traffic per pixel: fwd 8 B read (+12 B written when train), bwd 20 B read
 // + 4 B written; the kernel is HBM/L2-stream bound, the 1.72x halo re-read is
 // served by L2.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -203,6 +205,157 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
     }
   }
 
+// ---------------------------------------------------------------- forward, sliding window (round 4)
+// The tile kernel above spends most of its 72 us in its phase structure (stage -> barrier -> horizontal -> barrier ->
+// vertical, three workgroups per CU by the 42 KB of LDS each), not in memory: PMC traffic is 1.02x the algorithmic
+// bytes.  Here there is no LDS image and no barrier.  A WAVE owns a strip of SW_OUT = 54 output columns (lanes 5..58;
+// all 64 lanes hold input columns x0 - 5 .. x0 + 58) and walks a band of rows top to bottom:
+//   horizontal  the 11 taps of a row come from the neighbouring lanes through full-wave DPP shifts of the two input
+//               values (ten shifts per image), every output accumulates its taps in the order k = 0..10 with the tile
+//               kernel's operations;
+//   vertical    an input row's five statistics are added at once into the eleven output rows it belongs to (eleven
+//               accumulator sets in registers, slots static through an 11-fold unroll); output row r receives its taps
+//               in the order k = 0..10 as well, so every statistic is bit-identical to the tile kernel's;
+//   loads       one 256-byte row segment per image and input row, issued four rows ahead into a register ring.
+// Per input row and lane: 2 loads, 20 DPP moves, ~130 vector operations.
+constexpr int SW_OUT = 64 - 2 * HALO;   // output columns per wave
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ inline float dpp_wave(float v) {   // 0x138 wave_shr:1 (lane l takes lane l - 1), 0x130 wave_shl:1; edge lanes take 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
+    const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
+    int bands, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+    float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63;
+  // units = (plane, band, strip), strips fastest; the four waves of a workgroup take four neighbouring strips of one
+  // band, and every XCD label (blockIdx & 7) a contiguous range of workgroups, so that the 10-column / 10-row overlaps
+  // of neighbouring units meet in one L2 (see tile_walk above)
+  const long long units = (long long)planes * bands * strips;
+  const long long nblk = gridDim.x;
+  long long blk = blockIdx.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);
+  const long long unit = blk * 4 + (threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int strip = (int)(unit % strips), band = (int)((unit / strips) % bands);
+  const size_t plane_off = (size_t)(unit / ((long long)strips * bands)) * H * W;
+  const int x = strip * SW_OUT + lane - HALO;           // this lane's input (and, for lanes 5..58, output) column
+  const bool x_in = x >= 0 && x < W;
+  const bool x_out = lane >= HALO && lane < 64 - HALO && x < W;
+  const int yb = band * RB, ye = min(H, yb + RB);       // output rows [yb, ye)
+  const float* p1 = img1 + plane_off + (x_in ? x : 0);
+  const float* p2 = img2 + plane_off + (x_in ? x : 0);
+
+  constexpr int PFD = 4;     // input rows in flight ahead of the one being filtered
+  float ra[11], rb[11];      // slot t % 11 holds input row (yb - 5) + t; only PFD of them are live at a time
+  // pending output rows: slot (t + 5 - k) % 11 for the row that takes tap k of input row t; (mu1, mu2), (e11, e22), e12
+  v2f accm[11], accs[11];
+  float accx[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    ra[i] = 0.f; rb[i] = 0.f;
+    if (i < PFD) {
+      const int y = yb - HALO + i;
+      const bool in = x_in && y >= 0 && y < H;
+      const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
+      const float va = p1[o], vb = p2[o];
+      ra[i] = in ? va : 0.f;
+      rb[i] = in ? vb : 0.f;
+    }
+    accm[i] = v2f{0.f, 0.f}; accs[i] = v2f{0.f, 0.f}; accx[i] = 0.f;
+  }
+  float local = 0.f;
+  const int t_end = (ye - yb) + 2 * HALO;                // input rows yb - 5 .. ye + 4
+  for (int t0 = 0; t0 < t_end; t0 += 11) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int t = t0 + i;
+      if (t < t_end) {                                   // wave-uniform
+        const float a0 = ra[i], b0 = rb[i];
+        {   // the row PFD steps ahead
+          const int y = yb - HALO + t + PFD;
+          const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
+          const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
+          const float va = p1[o], vb = p2[o];
+          ra[(i + PFD) % 11] = in ? va : 0.f;
+          rb[(i + PFD) % 11] = in ? vb : 0.f;
+        }
+        // ---- horizontal: input columns x - 5 .. x + 5 of this row, tap k at column x - 5 + k
+        // (the left neighbours first — tap 0 is the FARTHEST one — then the right ones as the taps reach them, so that at
+        // most six values per image are live)
+        float al[6], bl[6];
+        al[0] = a0; bl[0] = b0;
+#pragma unroll
+        for (int j = 1; j <= 5; ++j) {
+          al[j] = dpp_wave<0x138>(al[j - 1]);            // lane l - j
+          bl[j] = dpp_wave<0x138>(bl[j - 1]);
+        }
+        // packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32: two IEEE operations per instruction, the same roundings as the
+        // scalar forms, so the statistics stay bit-identical to the tile kernel's): (m1, m2) and (s11, s22) travel as pairs
+        v2f m12 = {0.f, 0.f}, s1122 = {0.f, 0.f};
+        float s12 = 0.f;
+        auto tap = [&](float w, float a, float b) {
+          const v2f ab = {a, b};
+          const v2f wab = ab * w;
+          m12 += wab;
+          s1122 = __builtin_elementwise_fma(wab, ab, s1122);
+          s12 = fmaf(wab.x, b, s12);
+        };
+        tap(kWin[0], al[5], bl[5]); tap(kWin[1], al[4], bl[4]); tap(kWin[2], al[3], bl[3]);
+        tap(kWin[3], al[2], bl[2]); tap(kWin[4], al[1], bl[1]); tap(kWin[5], al[0], bl[0]);
+        float ar = a0, br = b0;
+#pragma unroll
+        for (int k = 6; k < 11; ++k) {
+          ar = dpp_wave<0x130>(ar);                      // lane l + (k - 5)
+          br = dpp_wave<0x130>(br);
+          tap(kWin[k], ar, br);
+        }
+        // ---- vertical: this input row is tap k of output row (yb - 5 + t) + 5 - k
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const int sl = (i + 5 - k + 11) % 11;
+          const float w = kWin[k];
+          const v2f ww = {w, w};
+          accm[sl] = __builtin_elementwise_fma(ww, m12, accm[sl]);
+          accs[sl] = __builtin_elementwise_fma(ww, s1122, accs[sl]);
+          accx[sl] = fmaf(w, s12, accx[sl]);
+        }
+        // ---- the output row that just took its last tap (k = 10): r = yb - 10 + t
+        const int sl = (i + 5 - 10 + 11) % 11;
+        const int r = yb - 2 * HALO + t;
+        if (r >= yb && r < ye && x_out) {
+          const float mu1 = accm[sl].x, mu2 = accm[sl].y, e11 = accs[sl].x, e22 = accs[sl].y, e12 = accx[sl];
+          const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+          const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
+          const float A1 = 2.f * mu12 + kC1;
+          const float A2 = 2.f * sig12 + kC2;
+          const float B1 = mu1_sq + mu2_sq + kC1;
+          const float B2 = sig1 + sig2 + kC2;
+          const float inv_B1 = 1.f / B1, inv_B2 = 1.f / B2;
+          const float m = (A1 * A2) * (inv_B1 * inv_B2);
+          local += m;
+          if (TRAIN) {
+            const float d_s1 = -m * inv_B2;
+            const float d_s12 = 2.f * A1 * inv_B1 * inv_B2;
+            const float d_mu1 = 2.f * mu2 * A2 * inv_B1 * inv_B2 - 2.f * mu1 * m * inv_B1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+            const size_t o = plane_off + (size_t)r * W + x;
+            dm_dmu1[o] = d_mu1;
+            dm_dsigma1_sq[o] = d_s1;
+            dm_dsigma12[o] = d_s12;
+          }
+        }
+        accm[sl] = v2f{0.f, 0.f}; accs[sl] = v2f{0.f, 0.f}; accx[sl] = 0.f;   // the slot now belongs to output row r + 11
+      }
+    }
+  }
+  local = wave_sum(local);
+  if (lane == 0) partials[unit] = local;
+}
+
   __global__ __launch_bounds__(NT) void ssim_reduce_kernel(const float* __restrict__ partials,
                                                             size_t n, double inv_count,
                                                             float* __restrict__ out) {
@@ -321,11 +474,140 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
     }
   }
 
+// ---------------------------------------------------------------- backward, sliding window (round 4)
+// The same walk as ssim_fwd_sw_kernel for the adjoint: the three derivative maps are filtered with the window in both
+// directions (taps in the order k = 0..10, fused multiply-adds as in the tile kernel: bit-identical), the output row
+// r = y - 5 is finished with the two images at (r, x):  dL/dimg1 = g (A + 2 img1 B + img2 D).
+__global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
+    const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
+    int bands, const float* __restrict__ dL_dmean, float inv_count, const float* __restrict__ dm_dmu1,
+    const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+  const int lane = threadIdx.x & 63;
+  const long long units = (long long)planes * bands * strips;
+  const long long nblk = gridDim.x;
+  long long blk = blockIdx.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);
+  const long long unit = blk * 4 + (threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int strip = (int)(unit % strips), band = (int)((unit / strips) % bands);
+  const size_t plane_off = (size_t)(unit / ((long long)strips * bands)) * H * W;
+  const int x = strip * SW_OUT + lane - HALO;
+  const bool x_in = x >= 0 && x < W;
+  const bool x_out = lane >= HALO && lane < 64 - HALO && x < W;
+  const int yb = band * RB, ye = min(H, yb + RB);
+  const size_t col = plane_off + (x_in ? x : 0);
+  const float g = dL_dmean[0] * inv_count;
+
+  constexpr int PFD = 4;
+  float r0[11], r1[11], r2[11];   // input rows of the three maps in flight (slot t % 11), PFD live
+  float i1[11], i2[11];           // the images at the output row that completes at step t (slot t % 11), PFD live
+  v2f accab[11];                  // pending output rows: (A, B) and D, slot (t + 5 - k) % 11
+  float accd[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    r0[i] = r1[i] = r2[i] = 0.f;
+    i1[i] = i2[i] = 0.f;
+    if (i < PFD) {
+      const int y = yb - HALO + i;
+      const bool in = x_in && y >= 0 && y < H;
+      const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
+      const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
+      r0[i] = in ? v0 : 0.f; r1[i] = in ? v1 : 0.f; r2[i] = in ? v2 : 0.f;
+      const int ro = yb - 2 * HALO + i;                       // output row finished at step i
+      const size_t oo = col + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
+      i1[i] = img1[oo]; i2[i] = img2[oo];
+    }
+    accab[i] = v2f{0.f, 0.f}; accd[i] = 0.f;
+  }
+  const int t_end = (ye - yb) + 2 * HALO;
+  for (int t0 = 0; t0 < t_end; t0 += 11) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int t = t0 + i;
+      if (t < t_end) {
+        const float c0 = r0[i], c1 = r1[i], c2 = r2[i];
+        const float px = i1[i], py = i2[i];
+        {   // PFD steps ahead: the maps' input row and the images' output row
+          const int y = yb - HALO + t + PFD;
+          const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
+          const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
+          const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
+          r0[(i + PFD) % 11] = in ? v0 : 0.f; r1[(i + PFD) % 11] = in ? v1 : 0.f; r2[(i + PFD) % 11] = in ? v2 : 0.f;
+          const int ro = yb - 2 * HALO + t + PFD;
+          const size_t oo = col + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
+          i1[(i + PFD) % 11] = img1[oo]; i2[(i + PFD) % 11] = img2[oo];
+        }
+        // ---- horizontal
+        float l0[6], l1[6], l2[6];
+        l0[0] = c0; l1[0] = c1; l2[0] = c2;
+#pragma unroll
+        for (int j = 1; j <= 5; ++j) {
+          l0[j] = dpp_wave<0x138>(l0[j - 1]);
+          l1[j] = dpp_wave<0x138>(l1[j - 1]);
+          l2[j] = dpp_wave<0x138>(l2[j - 1]);
+        }
+        v2f hab = {0.f, 0.f};
+        float hd = 0.f;
+        auto tap = [&](float w, float v0, float v1, float v2) {
+          const v2f ww = {w, w}, vv = {v0, v1};
+          hab = __builtin_elementwise_fma(ww, vv, hab);
+          hd = fmaf(w, v2, hd);
+        };
+        tap(kWin[0], l0[5], l1[5], l2[5]); tap(kWin[1], l0[4], l1[4], l2[4]); tap(kWin[2], l0[3], l1[3], l2[3]);
+        tap(kWin[3], l0[2], l1[2], l2[2]); tap(kWin[4], l0[1], l1[1], l2[1]); tap(kWin[5], l0[0], l1[0], l2[0]);
+        float q0 = c0, q1 = c1, q2 = c2;
+#pragma unroll
+        for (int k = 6; k < 11; ++k) {
+          q0 = dpp_wave<0x130>(q0); q1 = dpp_wave<0x130>(q1); q2 = dpp_wave<0x130>(q2);
+          tap(kWin[k], q0, q1, q2);
+        }
+        // ---- vertical
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const int sl = (i + 5 - k + 11) % 11;
+          const float w = kWin[k];
+          const v2f ww = {w, w};
+          accab[sl] = __builtin_elementwise_fma(ww, hab, accab[sl]);
+          accd[sl] = fmaf(w, hd, accd[sl]);
+        }
+        const int sl = (i + 5 - 10 + 11) % 11;
+        const int r = yb - 2 * HALO + t;
+        if (r >= yb && r < ye && x_out)
+          dL_dimg1[plane_off + (size_t)r * W + x] = g * (accab[sl].x + 2.f * px * accab[sl].y + py * accd[sl]);
+        accab[sl] = v2f{0.f, 0.f}; accd[sl] = 0.f;
+      }
+    }
+  }
+}
+
+  }  // namespace
+
+  namespace {
+  // rows per band of the sliding-window forward: enough waves to fill the chip six deep, at least 16 rows per band
+  // (a band re-reads 10 halo rows).  PINGS_SSIM_RB overrides (A/B runs); PINGS_SSIM_FWD=tile keeps the tile kernel.
+  int sw_rows_per_band(int planes, int H, int W) {
+    if (const char* e = getenv("PINGS_SSIM_RB")) { const int v = atoi(e); if (v > 0) return v; }
+    // as many bands as fit ONE resident round of waves (256 CUs x 4 SIMDs x 4 waves by the kernel's registers): a second,
+    // partly filled round costs more than the 10 halo rows a shorter band re-reads (1080p x 3: 24-row bands 0.076 ms,
+    // 32 0.071, 48 0.075, 64 0.070; the round-3 tile kernel 0.075)
+    const long long strips = pings::ceil_div(W, SW_OUT);
+    const long long want_bands = (256LL * 4 * 4) / (strips * planes);
+    long long rb = pings::ceil_div<long long>(H, want_bands > 0 ? want_bands : 1);
+    if (rb < 16) rb = 16;
+    if (rb > H) rb = H;
+    return (int)rb;
+  }
+  size_t sw_units(int planes, int H, int W) {
+    const int rb = sw_rows_per_band(planes, H, W);
+    return (size_t)planes * pings::ceil_div(H, rb) * pings::ceil_div(W, SW_OUT);
+  }
   }  // namespace
 
   PINGS_API size_t pings_ssim_partials_count(int planes, int H, int W) {
     if (planes <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)planes * pings::ceil_div(H, TS) * pings::ceil_div(W, TS);
+    const size_t tiles = (size_t)planes * pings::ceil_div(H, TS) * pings::ceil_div(W, TS);
+    const size_t units = sw_units(planes, H, W);
+    return tiles > units ? tiles : units;      // either forward kernel fits
   }
 
   PINGS_API int pings_ssim_forward(const float* img1, const float* img2, int planes, int H, int W,
@@ -338,7 +620,27 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
     PINGS_ARG_CHECK(!train || (dm_dmu1 && dm_dsigma1_sq && dm_dsigma12),
                     "train=1 needs the three derivative maps");
     hipStream_t st = pings::as_stream(stream);
-    const size_t n = pings_ssim_partials_count(planes, H, W);
+    const char* fwd_env = getenv("PINGS_SSIM_FWD");
+    if (!(fwd_env && fwd_env[0] == 't')) {      // default: the sliding-window kernel
+      const int rb = sw_rows_per_band(planes, H, W);
+      const int strips = pings::ceil_div(W, SW_OUT), bands = pings::ceil_div(H, rb);
+      const size_t units = (size_t)planes * bands * strips;
+      unsigned nblk = (unsigned)pings::ceil_div<size_t>(units, 4);
+      nblk = (nblk + 7u) & ~7u;                  // a multiple of eight: the XCD-contiguous numbering above
+      pings::prof::Scope ps("ssim_fwd", st);
+      if (train)
+        hipLaunchKernelGGL(ssim_fwd_sw_kernel<true>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
+                           bands, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials);
+      else
+        hipLaunchKernelGGL(ssim_fwd_sw_kernel<false>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
+                           bands, (float*)nullptr, (float*)nullptr, (float*)nullptr, partials);
+      PINGS_LAUNCH_CHECK();
+      const double inv_count = 1.0 / ((double)planes * H * W);
+      hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), dim3(NT), 0, st, partials, units, inv_count, out_mean);
+      PINGS_LAUNCH_CHECK();
+      return PINGS_OK;
+    }
+    const size_t n = (size_t)planes * pings::ceil_div(H, TS) * pings::ceil_div(W, TS);
     const dim3 grid((unsigned)(n < (size_t)PERSISTENT_WGS ? n : (size_t)PERSISTENT_WGS));
     pings::prof::Scope ps("ssim_fwd", st);
     if (train) {
@@ -365,9 +667,22 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
     PINGS_ARG_CHECK(planes > 0 && H > 0 && W > 0, "empty image");
     PINGS_ARG_CHECK(planes <= 65535, "too many planes");
     hipStream_t st = pings::as_stream(stream);
-    const size_t n = pings_ssim_partials_count(planes, H, W);
-    const dim3 grid((unsigned)(n < (size_t)PERSISTENT_WGS ? n : (size_t)PERSISTENT_WGS));
     const float inv_count = (float)(1.0 / ((double)planes * H * W));
+    const char* bwd_env = getenv("PINGS_SSIM_BWD");
+    if (!(bwd_env && bwd_env[0] == 't')) {      // default: the sliding-window kernel
+      const int rb = sw_rows_per_band(planes, H, W);
+      const int strips = pings::ceil_div(W, SW_OUT), bands = pings::ceil_div(H, rb);
+      const size_t units = (size_t)planes * bands * strips;
+      unsigned nblk = (unsigned)pings::ceil_div<size_t>(units, 4);
+      nblk = (nblk + 7u) & ~7u;
+      pings::prof::Scope ps("ssim_bwd", st);
+      hipLaunchKernelGGL(ssim_bwd_sw_kernel, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands,
+                         dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+      PINGS_LAUNCH_CHECK();
+      return PINGS_OK;
+    }
+    const size_t n = (size_t)planes * pings::ceil_div(H, TS) * pings::ceil_div(W, TS);
+    const dim3 grid((unsigned)(n < (size_t)PERSISTENT_WGS ? n : (size_t)PERSISTENT_WGS));
     pings::prof::Scope ps("ssim_bwd", st);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(NT), 0, st, img1, img2, planes, H, W, dL_dmean,
                        inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
