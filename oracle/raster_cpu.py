@@ -29,8 +29,10 @@ listed in DESIGN.md ("rasteriser semantics"): 16x16 tiles, sort key (tile, view
 depth) with ties broken by Gaussian index, 3-sigma radius, z <= 0.2 near cull,
 T < 1e-4 termination, `contributions` = sum of blend weights over pixels,
 depth normalised by max(alpha, 1e-10), un-normalised blended normals, the
-per-pixel depth clamp to +-3*max(scale) around the centre depth, tile rectangles = bounding
-box of the footprint ellipse cut at min(3 sigma, alpha = 1/255) (`radii` stays ceil(3 sqrt(lambda_max))).
+per-pixel depth clamp to +-3*max(scale) around the centre depth.  Tile rectangles: the published
+3DGS square of half-width ceil(3 sqrt(lambda_max)) minus the tiles in which no pixel can pass the
+alpha >= 1/255 test (`Settings.rect = "tight"`: output-identical to the square, `"3sigma"`; the truncating
+ellipse box of rounds 1-3 is `"ellipse"`); `radii` is the published one under every rule.
 
 The same code runs in float32 (to pin tile rectangles, radii and the sort order
 bit-exactly: the op order below is the one the HIP preprocess kernel follows,

@@ -571,6 +571,17 @@ constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles a
 #ifdef PINGS_MLP_STATS
 __device__ unsigned long long g_mlp_stats[8];
 #endif
+// scheduling barriers of mlp_bwd_wave_body: the operand reads of the NEXT product are pinned above the MFMAs of the
+// current one (A, C, D) and the mask below the products it depends on (B).  PINGS_MLP_SB (A/B builds, tools/mlp_sb_ab.sh):
+// bit k clear = barrier k left to the compiler.
+#ifndef PINGS_MLP_SB
+#define PINGS_MLP_SB 15
+#endif
+#define MLP_SB_(k_) do { if (PINGS_MLP_SB & (1 << (k_))) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MLP_SB_A MLP_SB_(0)
+#define MLP_SB_B MLP_SB_(1)
+#define MLP_SB_C MLP_SB_(2)
+#define MLP_SB_D MLP_SB_(3)
 
 // Round 4: the same five products, re-issued so that the matrix pipe does not wait for operands.
 //  * A PMC pass of round 3 put the pipe at 57 % busy; the ISA showed why: every LDS operand was fetched just in time
@@ -732,14 +743,14 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
       float opC[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) opC[q] = baseC[(hb * 32 + (q & 3) + 8 * (q >> 2)) * BW_LD];
-      __builtin_amdgcn_sched_barrier(0);
+      MLP_SB_A;
       f32x16 pre = {0}, gH = {0};
 #pragma unroll
       for (int s2 = 0; s2 < 17; ++s2) {
         pre = mfma(opA[s2], s2 < 16 ? xf[s2] : one, pre);
         if (s2 < OH) gH = mfma(opB[s2], gyf[s2], gH);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      MLP_SB_B;
       MLP_TICK(2);   // products A / B issued
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -761,13 +772,13 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         aH[s2] = rdH[s2];
         aG[s2] = rdG[s2];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      MLP_SB_C;
 #pragma unroll
       for (int q = 0; q < 16; ++q) gxacc = mfma(opC[q], gH[q], gxacc);   // (computed even when gx is null: no branch)
       MLP_TICK(4);   // transposes + product C issued
       // ---- the weight-gradient products; meanwhile the operands of the next hidden block's A and B
       load_AB((hb + 1) & 3);
-      __builtin_amdgcn_sched_barrier(0);
+      MLP_SB_D;
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
         aB1[hb] += aG[s2];

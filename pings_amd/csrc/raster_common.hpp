@@ -118,6 +118,8 @@ struct BinState {
   uint32_t seg_max_units;      // capacity: every list of more than 2 * SEG entries cut into SEG-entry units
   uint32_t *seg_head, *seg_unit_tile, *seg_unit_seg, *seg_tile_unit0;
   float *seg_P, *seg_slab;
+  uint16_t* seg_rel;           // [units][4][SEG] pass T's compacted list: offsets (in the segment) of the entries that can
+  uint32_t* seg_nrel;          // [units][4]      reach the quadrant, and how many — pass B walks these instead of re-testing
   char* temp;
   size_t temp_bytes;
   size_t total;

@@ -587,11 +587,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
   // (a band re-reads 10 halo rows).  PINGS_SSIM_RB overrides (A/B runs); PINGS_SSIM_FWD=tile keeps the tile kernel.
   int sw_rows_per_band(int planes, int H, int W) {
     if (const char* e = getenv("PINGS_SSIM_RB")) { const int v = atoi(e); if (v > 0) return v; }
-    // as many bands as fit ONE resident round of waves (256 CUs x 4 SIMDs x 4 waves by the kernel's registers): a second,
-    // partly filled round costs more than the 10 halo rows a shorter band re-reads (1080p x 3: 24-row bands 0.076 ms,
-    // 32 0.071, 48 0.075, 64 0.070; the round-3 tile kernel 0.075)
+    // about three waves per SIMD in all (the kernels hold four): fewer, taller bands re-read fewer halo rows, more bands
+    // balance the chip better.  1080p x 3, forward / backward ms by band height: 20 rows 0.075 / 0.049, 24 0.069 / 0.046,
+    // 28 0.071 / 0.048, 32 0.066 / 0.044, 40 0.063 / 0.042, 64 0.065 / 0.043 (the round-3 tile kernels: 0.074 / 0.050)
     const long long strips = pings::ceil_div(W, SW_OUT);
-    const long long want_bands = (256LL * 4 * 4) / (strips * planes);
+    const long long want_bands = (256LL * 4 * 3) / (strips * planes);
     long long rb = pings::ceil_div<long long>(H, want_bands > 0 ? want_bands : 1);
     if (rb < 16) rb = 16;
     if (rb > H) rb = H;

@@ -584,11 +584,15 @@ def _rect_scene(kind):
     return scene_as_dict(*street_scene(24000, device="cpu", seed=3), 348, 128, 180.0)
 
 
+_KS, _KP4, _KP1 = ("-1", "scan", ""), ("4", "pixel", "4"), ("1", "pixel", "1")
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernels", [("-1", "scan", ""), ("4", "pixel", "4"), ("1", "pixel", "1")])
-@pytest.mark.parametrize("kind,mode,front_only", [("random", "surfel", True), ("random_thin", "surfel", False),
-                                                   ("random", "3dgs", True), ("cloud", "surfel", True),
-                                                   ("street", "surfel", True)])
+@pytest.mark.parametrize("kind,mode,front_only,kernels", [
+    ("random", "surfel", True, _KS), ("random", "surfel", True, _KP4), ("random", "surfel", True, _KP1),
+    ("random_thin", "surfel", False, _KS), ("random_thin", "surfel", False, _KP4),
+    ("random", "3dgs", True, _KS), ("random", "3dgs", True, _KP4),
+    ("cloud", "surfel", True, _KP4), ("cloud", "surfel", True, _KS), ("street", "surfel", True, _KS)])
 def test_default_rectangle_is_lossless(kind, mode, front_only, kernels, monkeypatch):
     """VERDICT r3 #1.  The default tile rectangle (published 3 sigma square of 3DGS getRect(), reached through
     gaussian_renderer/__init__.py:318-326, minus the tiles in which no pixel can pass alpha >= 1/255) against
@@ -977,8 +981,9 @@ def test_long_lists_blended_in_parallel_segments(mode, monkeypatch):
     sc = make_scene(5000, W, H, seed=91, surfel=(mode == "surfel"), smin=0.05, smax=0.5)
     sc["op"] = sc["op"] * 0.25                                  # translucent: lists are walked deep
 
-    def run(seg):
+    def run(seg, reuse="1"):
         monkeypatch.setenv("PINGS_BLEND_SEG", seg)
+        monkeypatch.setenv("PINGS_BLEND_SEG_REUSE", reuse)
         monkeypatch.setenv("PINGS_RASTER_OCCLUSION", "0")
         monkeypatch.setenv("PINGS_BLEND_PPL", "-1")
         monkeypatch.setenv("PINGS_BLEND_BWD", "scan")
@@ -1000,6 +1005,11 @@ def test_long_lists_blended_in_parallel_segments(mode, monkeypatch):
     out_s, g_s, nc_s, longest = run("64")
     out_0, g_0, nc_0, _ = run("0")
     assert longest > 4 * 64, longest                           # several segments per tile
+    # pass B on pass T's compacted lists (round 4, the default) against pass B re-testing every entry: the same
+    # entries in the same order, bit for bit
+    out_r, g_r, nc_r, _ = run("64", reuse="0")
+    assert all(torch.equal(a, b) for a, b in zip(out_s, out_r)) and torch.equal(nc_s, nc_r)
+    assert all(torch.equal(a, b) for a, b in zip(g_s, g_r))
     for a, b in zip(out_s, out_0):
         if a.is_floating_point():
             assert rel_err(a, b) <= 1e-5

@@ -1,10 +1,10 @@
 #!/bin/bash
-# One GPU-box pass of a round (outputs under gpurun_out/r03<tag>): usage (repo root on the box): bash tools/gpu_round.sh <tag> <part>
+# One GPU-box pass of a round (outputs under gpurun_out/r04<tag>): usage (repo root on the box): bash tools/gpu_round.sh <tag> <part>
 # part 1: tests + smoke + bench;  part 2: rocprofv3 kernel stats + PMC passes + 2-rank rehearsal
 set -o pipefail
 tag=${1:-x}; part=${2:-1}
 R=$PWD
-O=$R/gpurun_out/r03$tag
+O=$R/gpurun_out/r04$tag
 mkdir -p $O
 export TMPDIR=/tmp
 if [ "$part" = "1" ]; then
