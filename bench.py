@@ -143,6 +143,9 @@ def best_threads(fn, candidates=(8, 16, 32, 64, 128)):
     return torch.get_num_threads()
 
 
+# fp32 operations per vector instruction in the record loop of blend_bwd_kernel<0,4> (tools/valu_mix.py on the gfx950 ISA)
+BLEND_BWD_FLOPS_PER_VALU = 0.99
+
 # largest fraction of (pixels, Gaussians) the parity gates may set aside as "undecidable in fp32" per test scene
 # (measured in round 4: street 0.034 % / 21.6 %, room 0.036 % / 5.5 %, cloud 27.8 % / 21.0 % — the pixel
 # ceilings are the verdict's, the Gaussian ceilings twice the measured values)
@@ -1284,7 +1287,16 @@ def main():
                     # committed PMC pass) / measured time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op
                     "valu": None if not valu_insts else {
                         "wave_insts": int(valu_insts), "achieved_Ginst_s": round(valu_insts / (per[dom] * 1e-3) / 1e9, 1),
-                        "peak_Ginst_s": 1228.8, "frac": round(valu_insts / (per[dom] * 1e-3) / 1228.8e9, 4)},
+                        "peak_Ginst_s": 1228.8, "frac": round(valu_insts / (per[dom] * 1e-3) / 1228.8e9, 4),
+                        # fp32 flops next to the issue fraction.  Executed flops = wave-instructions x 64
+                        # lanes x the flops per vector instruction of the kernel's record loop (static mix of
+                        # blend_bwd_kernel<0,4>'s ISA: 362 vector instructions, 360 fp32 operations counting an fma as two
+                        # and a packed op as two lanes - selects, compares and moves carry none), every lane counted as
+                        # active: an UPPER bound of the useful work, against the 157.3 TFLOP/s fp32 vector peak
+                        "flops_per_valu_inst": BLEND_BWD_FLOPS_PER_VALU,
+                        "TFLOP_s": round(valu_insts * 64 * BLEND_BWD_FLOPS_PER_VALU / (per[dom] * 1e-3) / 1e12, 1),
+                        "peak_TFLOP_s": 157.3,
+                        "flop_frac": round(valu_insts * 64 * BLEND_BWD_FLOPS_PER_VALU / (per[dom] * 1e-3) / 157.3e12, 4)},
                     "avg_ms": round(per[dom], 4), "launches_timed": prof[dom][0], "algorithmic_bytes": int(alg[dom]),
                     "measured": "HIP events around this kernel on its launch stream, inside the timed region; the "
                                 "other stages ('kernels') come from the warm-up steps with every stage recorded",

@@ -571,11 +571,13 @@ constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles a
 #ifdef PINGS_MLP_STATS
 __device__ unsigned long long g_mlp_stats[8];
 #endif
-// scheduling barriers of mlp_bwd_wave_body: the operand reads of the NEXT product are pinned above the MFMAs of the
-// current one (A, C, D) and the mask below the products it depends on (B).  PINGS_MLP_SB (A/B builds, tools/mlp_sb_ab.sh):
-// bit k clear = barrier k left to the compiler.
+// Optional scheduling barriers of mlp_bwd_wave_body (bit k of PINGS_MLP_SB = barrier k; A/B builds, tools/mlp_sb_ab.sh):
+// A, C, D pin the operand reads of the NEXT product above the MFMAs of the current one, B the mask below the products
+// it depends on.  Measured at 125k points, five decoders (ms): all four 0.306, A 0.310, A + C 0.307, A + C + D 0.309,
+// A + B + C 0.300, NONE 0.281 — the source order (reads of the next product written ahead of the current product's
+// MFMAs) is enough for the compiler's scheduler, and hard barriers only keep it from overlapping the tails: default none.
 #ifndef PINGS_MLP_SB
-#define PINGS_MLP_SB 15
+#define PINGS_MLP_SB 0
 #endif
 #define MLP_SB_(k_) do { if (PINGS_MLP_SB & (1 << (k_))) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MLP_SB_A MLP_SB_(0)
