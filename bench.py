@@ -788,7 +788,8 @@ def ssim_pmc_traffic(W, H):
     try:
         files = sorted(os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith("ssim_pmc_traffic.json"))
         data = json.load(open(files[-1]))
-        tot = sum(v["hbm_bytes_corrected"] for k, v in data.items() if k.startswith("ssim_fwd_kernel") or k.startswith("ssim_bwd_kernel"))
+        # (ssim_fwd_kernel / ssim_bwd_kernel: the tile kernels of rounds 1-3; ssim_*_sw_kernel: the sliding-window ones)
+        tot = sum(v["hbm_bytes_corrected"] for k, v in data.items() if k.startswith(("ssim_fwd_", "ssim_bwd_")))
         return int(tot) or None
     except Exception:
         return None

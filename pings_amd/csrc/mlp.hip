@@ -580,6 +580,12 @@ __device__ unsigned long long g_mlp_stats[8];
 #define PINGS_MLP_SB 0
 #endif
 #define MLP_SB_(k_) do { if (PINGS_MLP_SB & (1 << (k_))) __builtin_amdgcn_sched_barrier(0); } while (0)
+// The wave barriers around the wave-private LDS round trips (tile views; before / after the transpose writes) are NOT
+// optional: builds without the two around the transposes were no faster (0.285-0.288 ms) and failed tests/test_mlp.py —
+// the compiler does move the transposed reads across the writes without the fence.
+#define MLP_WB_T __builtin_amdgcn_wave_barrier()
+#define MLP_WB_W __builtin_amdgcn_wave_barrier()
+#define MLP_WB_R __builtin_amdgcn_wave_barrier()
 #define MLP_SB_A MLP_SB_(0)
 #define MLP_SB_B MLP_SB_(1)
 #define MLP_SB_C MLP_SB_(2)
@@ -719,7 +725,7 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
     // the next tile's rows: in flight for the whole of this tile, staged into the other LDS buffer at its end
     // (beyond the last tile the clamped addresses re-read row N - 1 and the values are never used)
     fetch_rows(t + nwaves, xn, gn);
-    __builtin_amdgcn_wave_barrier();
+    MLP_WB_T;
     float xf[16], gyf[OH], xcol[16], gycol[16];
     {
       const float* bxr = myX + buf * 32 * BW_LD + r * BW_LD + 16 * h;     // row view
@@ -761,13 +767,13 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
       }
       MLP_TICK(3);   // mask (waits for the products)
       // ---- product C; meanwhile H^T and gH^T take their trip through the wave's private LDS ([hid_local][row])
-      __builtin_amdgcn_wave_barrier();
+      MLP_WB_W;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         wrH[((q & 3) + 8 * (q >> 2)) * BW_LD] = pre[q];
         wrG[((q & 3) + 8 * (q >> 2)) * BW_LD] = gH[q];
       }
-      __builtin_amdgcn_wave_barrier();
+      MLP_WB_R;
       float aH[16], aG[16];
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {

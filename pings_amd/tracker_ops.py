@@ -4,8 +4,9 @@
 gradient, spread of the per-neighbour predictions, marching-cubes / registration mask and certainty of every source
 point come from ONE fused kernel launch per batch (`pings_sdf_forward`: hash-grid kNN + feature gather + decoder +
 IDW + d/dx), where the reference runs query_feature, the decoder, an autograd backward through all of it and a
-dozen element-wise kernels, 50-100 times per frame.  Colour / semantic queries, which only the photometric term
-needs, reuse the HIP-backed `query_feature` with the reference's own torch tail.
+dozen element-wise kernels, 50-100 times per frame.  Colour and semantic queries without a gradient run HIP
+`query_feature`, the head's decoder on the fused kernels and `pings_head_reduce`; the colour gradient of the photometric
+term (`query_color_grad`) keeps the reference's torch tail behind the HIP `query_feature`.
 
 `implicit_reg` — drop-in for the module-level function (utils/tracker.py:608-689): the 6x6 normal equations come from
 `pings_reg_normal_equations` (one pass, fp64 accumulation, fixed-order reduction); LM damping, the fp64 6x6 solve and
@@ -115,8 +116,6 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
     (sdf_pred, sdf_grad, color_pred, color_grad, sem_pred, mc_mask, certainty, sdf_std)."""
     if not coord.is_cuda:
         raise _lib.PingsHipError("query_source_points runs on the HIP device only; there is no CPU fallback")
-    if query_sem:
-        raise NotImplementedError("semantic head: outside the PINGS hot path (no shipped config enables it)")
     n = coord.shape[0]
     dev = coord.device
     iters = math.ceil(n / bs) if n else 0
@@ -129,6 +128,7 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
     channels = getattr(self.config, "color_channel", 3)
     color_pred = torch.zeros(n, channels, device=dev) if query_color else None
     color_grad = torch.zeros(n, channels, 3, device=dev) if query_color_grad else None
+    sem_pred = torch.zeros(n, device=dev) if query_sem else None
     npm = self.neural_points
     for k in range(iters):
         head, tail = k * bs, min((k + 1) * bs, n)
@@ -156,7 +156,23 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
                     mc_mask[head:tail] = cnt >= mask_min_nn_count
                 if query_certainty:
                     certainty[head:tail] = cert
-        if query_color:   # photometric term only: HIP-backed query_feature + the reference's torch tail (:322-331)
+        if query_sem or (query_color and not query_color_grad):
+            # heads without a gradient w.r.t. the query (:322-331): HIP query_feature, the head's decoder on the fused
+            # MFMA kernels and one activation + IDW-sum (+ arg-max) pass (csrc/heads.hip), as in the mesher
+            from . import decoder as _dec
+            from .mesher_ops import head_reduce
+
+            with torch.no_grad():
+                gf, cf, w_knn, _, _ = npm.query_feature(x.detach(), accumulate_stability=False, query_locally=query_locally,
+                                                        query_geo_feature=bool(query_sem),
+                                                        query_color_feature=bool(query_color and not query_color_grad),
+                                                        use_only_valid_points=True)
+                wk = None if self.config.weighted_first else w_knn
+                if query_sem:
+                    sem_pred[head:tail] = head_reduce(_dec.mlp(self.sem_mlp, gf), wk, 1).to(sem_pred.dtype)
+                if query_color and not query_color_grad:
+                    color_pred[head:tail] = head_reduce(_dec.mlp(self.color_mlp, cf), wk, 0)
+        if query_color and query_color_grad:   # photometric term with its gradient: HIP query_feature + the reference's torch tail
             xc = x.detach().clone().requires_grad_(bool(query_color_grad))
             _, color_feature, w_knn, _, _ = npm.query_feature(xc, accumulate_stability=False, query_locally=query_locally,
                                                               query_color_feature=True, use_only_valid_points=True)
@@ -168,7 +184,7 @@ def query_source_points(self, coord, bs, query_sdf=True, query_sdf_grad=True, qu
                     (gi,) = torch.autograd.grad(col[:, i].sum(), xc, retain_graph=True)
                     color_grad[head:tail, i, :] = gi.detach()
             color_pred[head:tail] = col.detach()
-    return sdf_pred, sdf_grad, color_pred, color_grad, None, mc_mask, certainty, sdf_std
+    return sdf_pred, sdf_grad, color_pred, color_grad, sem_pred, mc_mask, certainty, sdf_std
 
 
 def install(tracker_module) -> None:

@@ -38,6 +38,7 @@ FETCH_FACTOR = {
     "blend_fwd_tile_kernel": (1.0, "64-B aligned records; its pixel traffic is writes"),
     "blend_fwd_wave_kernel": (1.0, "64-B aligned records"),
     "blend_fwd_seg_kernel": (1.0, "64-B aligned records"),
+    "blend_fwd_wave_segT_kernel": (1.0, "64-B aligned records"),
     "sdf_forward": (1.0, "32-B block entries / records and 4..128-B row gathers: half-line requests (exact)"),
     "qf_forward_kernel": (1.0, "as sdf_forward"),
     "knn_search_kernel": (1.0, "as sdf_forward"),

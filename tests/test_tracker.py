@@ -113,6 +113,29 @@ def test_hip_query_source_points_matches_reference(golden_dir, name):
     assert (std.cpu() - T(ref[f"qsp_{name}_std"])).abs().max() <= TOL * max(float(np.abs(ref[f"qsp_{name}_sdf"]).max()), 1e-3)
 
 
+@pytest.mark.gpu
+def test_hip_query_source_points_heads_equal_the_meshers(golden_dir):
+    """`query_sem` / `query_color` of `Tracker.query_source_points` (utils/tracker.py:322-331) are the mesher's heads
+    (utils/mesher.py:132-153) on other query points: same kernels, checked here against `Mesher.query_points` on the
+    G11 grid, which the G11b vectors pin to the reference."""
+    from pings_amd import mesher_ops as MO, tracker_ops as TO
+    from test_mesher import _HeadDec
+
+    name = "gs_f32"
+    st = load(golden_dir, name)
+    z = np.load(golden_dir / "mesher_heads.npz")
+    ref = {k: z[k] for k in z.files}
+    coord = T(np.load(golden_dir / "mesher_grid.npz")[f"{name}_coord"]).cuda()
+    fake = NS(neural_points=_gpu_map(st), sdf_mlp=_Dec(st), sem_mlp=_HeadDec(ref, f"{name}_sem"),
+              color_mlp=_HeadDec(ref, f"{name}_col"), config=NS(weighted_first=bool(st["weighted_first"]), color_channel=3))
+    out = TO.query_source_points(fake, coord, 2000, False, False, True, False, True, query_mask=False,
+                                 query_certainty=False, query_locally=False)
+    _, sem_m, col_m, _ = MO.query_points(fake, coord, 2000, False, True, True, False, query_locally=False, out_torch=True)
+    assert out[0] is None and out[3] is None
+    assert torch.equal(out[2].cpu(), col_m) and torch.equal(out[4].cpu(), sem_m)
+    assert np.abs(out[2].cpu().numpy() - ref[f"{name}_color"]).max() <= 1e-5
+
+
 def test_tracker_product_path_rejects_host_tensors():
     from pings_amd import _lib, tracker_ops as TO
 

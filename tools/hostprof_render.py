@@ -37,3 +37,29 @@ with profile(activities=[ProfilerActivity.CPU]) as prof:
         fn()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cpu_time_total", row_limit=60, max_name_column_width=60))
+
+# ---- where the GPU idles inside an iteration: gaps between consecutive device activities of one profiled window
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof2:
+    for _ in range(6):
+        fn()
+    torch.cuda.synchronize()
+dev_ev = sorted([e for e in prof2.events() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()
+                 and e.time_range.end > e.time_range.start], key=lambda e: e.time_range.start)
+if dev_ev:
+    busy = sum(e.time_range.end - e.time_range.start for e in dev_ev)
+    span = dev_ev[-1].time_range.end - dev_ev[0].time_range.start
+    print(f"device activities {len(dev_ev)}, busy {busy / 6 / 1e3:.3f} ms / iteration, span {span / 6 / 1e3:.3f} ms / iteration")
+    gaps = []
+    for a, b in zip(dev_ev[:-1], dev_ev[1:]):
+        g = b.time_range.start - a.time_range.end
+        if g > 3:
+            gaps.append((g, a.name[:60], b.name[:60]))
+    from collections import defaultdict
+    agg = defaultdict(lambda: [0, 0.0])
+    for g, a, b in gaps:
+        agg[(a, b)][0] += 1
+        agg[(a, b)][1] += g
+    print("largest idle gaps (us per iteration | count per iteration | after -> before):")
+    for (a, b), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"  {t / 6:8.1f}  {n / 6:5.1f}   {a}  ->  {b}")
+    print(f"total idle in gaps > 3 us: {sum(g for g, _, _ in gaps) / 6 / 1e3:.3f} ms / iteration")

@@ -4,7 +4,7 @@
 #   bash tools/mlp_sb_ab.sh run     (GPU box)   ->  one dec_bench line per variant
 R=$(cd "$(dirname "$0")/.." && pwd)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I$R/include -I$R/pings_amd/csrc -DPINGS_BUILDING_DLL"
-MASKS="0 1 5 13 7"
+MASKS=${MASKS:-"0 1 5 13 7"}
 if [ "$1" = "build" ]; then
   mkdir -p $R/profiles/_build/sb
   for m in $MASKS; do
