@@ -1063,6 +1063,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sdf", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--exchange-leg", action="store_true",
+                    help="N > 1: run the render_step_exchange leg even with --no-sdf (rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -1246,7 +1248,7 @@ def main():
 
     # N > 1: the real multi-view mapping step (every rank takes part: collectives inside), VERDICT r3 #7
     rse = None
-    if world > 1 and not args.no_sdf:
+    if world > 1 and (not args.no_sdf or args.exchange_leg):
         try:
             rse = bench_render_step(dev, max(args.steps // 2, 5), 2, exchange=(world, rank))
         except Exception as e:  # noqa: BLE001
@@ -1384,11 +1386,11 @@ def main():
             leg("raster_rect_3sigma", lambda: rect_leg("3sigma"))
             leg("raster_rect_ellipse", lambda: rect_leg("ellipse"))
             leg("render_step", lambda: bench_render_step(dev, ks, kw))
-            if rse is not None:
-                extras["render_step_exchange"] = rse
             leg("decoder", lambda: bench_decoder(dev, ks, kw))
             leg("map_maintenance", lambda: bench_map(dev, with_cpu=not args.no_cpu_baseline))
             leg("image_losses", lambda: bench_image_losses(dev, ks, kw, with_cpu=not args.no_cpu_baseline))
+        if rse is not None:
+            extras["render_step_exchange"] = rse
         decoder, map_maint, img_losses = extras.pop("decoder", None), extras.pop("map_maintenance", None), \
             extras.pop("image_losses", None)
         line = {

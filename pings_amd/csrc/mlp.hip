@@ -583,9 +583,10 @@ __device__ unsigned long long g_mlp_stats[8];
 // The wave barriers around the wave-private LDS round trips (tile views; before / after the transpose writes) are NOT
 // optional: builds without the two around the transposes were no faster (0.285-0.288 ms) and failed tests/test_mlp.py —
 // the compiler does move the transposed reads across the writes without the fence.
-#define MLP_WB_T __builtin_amdgcn_wave_barrier()
-#define MLP_WB_W __builtin_amdgcn_wave_barrier()
-#define MLP_WB_R __builtin_amdgcn_wave_barrier()
+// (wave barrier = scheduling fence; the empty asm with a memory clobber states the memory ordering explicitly)
+#define MLP_WB_T do { __builtin_amdgcn_wave_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
+#define MLP_WB_W MLP_WB_T
+#define MLP_WB_R MLP_WB_T
 #define MLP_SB_A MLP_SB_(0)
 #define MLP_SB_B MLP_SB_(1)
 #define MLP_SB_C MLP_SB_(2)

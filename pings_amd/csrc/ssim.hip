@@ -229,7 +229,7 @@ __device__ inline float dpp_wave(float v) {   // 0x138 wave_shr:1 (lane l takes 
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
     const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
-    int bands, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+    int bands, int alt, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
     float* __restrict__ partials) {
   const int lane = threadIdx.x & 63;
   // units = (plane, band, strip), strips fastest; the four waves of a workgroup take four neighbouring strips of one
@@ -247,6 +247,14 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
   const bool x_in = x >= 0 && x < W;
   const bool x_out = lane >= HALO && lane < 64 - HALO && x < W;
   const int yb = band * RB, ye = min(H, yb + RB);       // output rows [yb, ye)
+  // Odd bands walk bottom-up (alt): a band's last rows are then its lower neighbour's FIRST rows' neighbours in time as
+  // well as in space, so the ten halo rows two bands share are read by both within a few row steps and the second read
+  // hits the XCD's L2 (walking every band top-down, band i reads them ~RB steps after band i + 1 did: 40 us and 8 MB of
+  // other rows later — PMC: 1.23x the algorithmic bytes).  The window is symmetric, so a reversed band applies the same
+  // eleven weights; its outputs add their taps in the opposite row order (fp32 association: ~1e-7 relative).
+  const bool up = alt && (band & 1);
+  const int y_first = up ? ye + HALO - 1 : yb - HALO, y_step = up ? -1 : 1;      // input row of step t: y_first + t y_step
+  const int r_first = up ? ye + 2 * HALO - 1 : yb - 2 * HALO;                    // output row finished at step t
   const float* p1 = img1 + plane_off + (x_in ? x : 0);
   const float* p2 = img2 + plane_off + (x_in ? x : 0);
 
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
   for (int i = 0; i < 11; ++i) {
     ra[i] = 0.f; rb[i] = 0.f;
     if (i < PFD) {
-      const int y = yb - HALO + i;
+      const int y = y_first + i * y_step;
       const bool in = x_in && y >= 0 && y < H;
       const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
       const float va = p1[o], vb = p2[o];
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
       if (t < t_end) {                                   // wave-uniform
         const float a0 = ra[i], b0 = rb[i];
         {   // the row PFD steps ahead
-          const int y = yb - HALO + t + PFD;
+          const int y = y_first + (t + PFD) * y_step;
           const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
           const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
           const float va = p1[o], vb = p2[o];
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
         }
         // ---- the output row that just took its last tap (k = 10): r = yb - 10 + t
         const int sl = (i + 5 - 10 + 11) % 11;
-        const int r = yb - 2 * HALO + t;
+        const int r = r_first + t * y_step;
         if (r >= yb && r < ye && x_out) {
           const float mu1 = accm[sl].x, mu2 = accm[sl].y, e11 = accs[sl].x, e22 = accs[sl].y, e12 = accx[sl];
           const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
 // r = y - 5 is finished with the two images at (r, x):  dL/dimg1 = g (A + 2 img1 B + img2 D).
 __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
     const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
-    int bands, const float* __restrict__ dL_dmean, float inv_count, const float* __restrict__ dm_dmu1,
+    int bands, int alt, const float* __restrict__ dL_dmean, float inv_count, const float* __restrict__ dm_dmu1,
     const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
   const int lane = threadIdx.x & 63;
   const long long units = (long long)planes * bands * strips;
@@ -495,6 +503,9 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
   const bool x_in = x >= 0 && x < W;
   const bool x_out = lane >= HALO && lane < 64 - HALO && x < W;
   const int yb = band * RB, ye = min(H, yb + RB);
+  const bool up = alt && (band & 1);                       // odd bands bottom-up, see ssim_fwd_sw_kernel
+  const int y_first = up ? ye + HALO - 1 : yb - HALO, y_step = up ? -1 : 1;
+  const int r_first = up ? ye + 2 * HALO - 1 : yb - 2 * HALO;
   const size_t col = plane_off + (x_in ? x : 0);
   const float g = dL_dmean[0] * inv_count;
 
@@ -508,12 +519,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
     r0[i] = r1[i] = r2[i] = 0.f;
     i1[i] = i2[i] = 0.f;
     if (i < PFD) {
-      const int y = yb - HALO + i;
+      const int y = y_first + i * y_step;
       const bool in = x_in && y >= 0 && y < H;
       const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
       const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
       r0[i] = in ? v0 : 0.f; r1[i] = in ? v1 : 0.f; r2[i] = in ? v2 : 0.f;
-      const int ro = yb - 2 * HALO + i;                       // output row finished at step i
+      const int ro = r_first + i * y_step;                    // output row finished at step i
       const size_t oo = col + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
       i1[i] = img1[oo]; i2[i] = img2[oo];
     }
@@ -528,12 +539,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
         const float c0 = r0[i], c1 = r1[i], c2 = r2[i];
         const float px = i1[i], py = i2[i];
         {   // PFD steps ahead: the maps' input row and the images' output row
-          const int y = yb - HALO + t + PFD;
+          const int y = y_first + (t + PFD) * y_step;
           const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
           const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
           const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
           r0[(i + PFD) % 11] = in ? v0 : 0.f; r1[(i + PFD) % 11] = in ? v1 : 0.f; r2[(i + PFD) % 11] = in ? v2 : 0.f;
-          const int ro = yb - 2 * HALO + t + PFD;
+          const int ro = r_first + (t + PFD) * y_step;
           const size_t oo = col + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
           i1[(i + PFD) % 11] = img1[oo]; i2[(i + PFD) % 11] = img2[oo];
         }
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
           accd[sl] = fmaf(w, hd, accd[sl]);
         }
         const int sl = (i + 5 - 10 + 11) % 11;
-        const int r = yb - 2 * HALO + t;
+        const int r = r_first + t * y_step;
         if (r >= yb && r < ye && x_out)
           dL_dimg1[plane_off + (size_t)r * W + x] = g * (accab[sl].x + 2.f * px * accab[sl].y + py * accd[sl]);
         accab[sl] = v2f{0.f, 0.f}; accd[sl] = 0.f;
@@ -596,6 +607,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
     if (rb < 16) rb = 16;
     if (rb > H) rb = H;
     return (int)rb;
+  }
+  // odd bands bottom-up (halo rows meet in L2); PINGS_SSIM_ALT=0: every band top-down (bit-identical to the tile kernels)
+  int sw_alternate() {
+    if (const char* e = getenv("PINGS_SSIM_ALT")) return atoi(e) != 0;
+    return 1;
   }
   size_t sw_units(int planes, int H, int W) {
     const int rb = sw_rows_per_band(planes, H, W);
@@ -630,10 +646,10 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
       pings::prof::Scope ps("ssim_fwd", st);
       if (train)
         hipLaunchKernelGGL(ssim_fwd_sw_kernel<true>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
-                           bands, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials);
+                           bands, sw_alternate(), dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials);
       else
         hipLaunchKernelGGL(ssim_fwd_sw_kernel<false>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
-                           bands, (float*)nullptr, (float*)nullptr, (float*)nullptr, partials);
+                           bands, sw_alternate(), (float*)nullptr, (float*)nullptr, (float*)nullptr, partials);
       PINGS_LAUNCH_CHECK();
       const double inv_count = 1.0 / ((double)planes * H * W);
       hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), dim3(NT), 0, st, partials, units, inv_count, out_mean);
@@ -677,7 +693,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
       nblk = (nblk + 7u) & ~7u;
       pings::prof::Scope ps("ssim_bwd", st);
       hipLaunchKernelGGL(ssim_bwd_sw_kernel, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands,
-                         dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+                         sw_alternate(), dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
       PINGS_LAUNCH_CHECK();
       return PINGS_OK;
     }

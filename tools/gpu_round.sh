@@ -35,7 +35,13 @@ else
   python profiles/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $O/pmc_traffic.json $O/pmc_sq/q_counter_collection.csv '{"gaussians": 1000000, "width": 1920, "height": 1080, "mode": "surfel"}' > $O/pmc_summary.txt 2>&1; echo "pmc summary rc=$?"
   python profiles/pmc_summary.py $O/ssim_FETCH_SIZE/p_counter_collection.csv $O/ssim_WRITE_SIZE/p_counter_collection.csv $O/ssim_pmc_traffic.json > $O/ssim_pmc_summary.txt 2>&1; echo "ssim summary rc=$?"
   cp $O/prof/s_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
-  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --single-device --no-sdf --no-cpu-baseline > $O/bench_2rank_gloo.log 2>&1; echo "2-rank rehearsal rc=$?"
+  # C3 street workload alone (kernel statistics) and the decoder kernels' matrix-pipe counters
+  cd /tmp
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o c -- python3 $R/tools/raster_only.py c3 40 > $O/c3.log 2>&1; echo "c3 stats rc=$?"
+  cd $R
+  cp $O/c3/c_kernel_stats.csv $O/c3_kernel_stats.csv 2>/dev/null
+  bash tools/pmc_mlp.sh > $O/mlp_pmc.txt 2>&1; echo "mlp pmc rc=$?"
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --single-device --no-sdf --no-cpu-baseline --exchange-leg > $O/bench_2rank_gloo.log 2>&1; echo "2-rank rehearsal rc=$?"
   tail -c 300 $O/bench_2rank_gloo.log
   find $O -type f -size +12M -delete
   find $O -name "*kernel_trace.csv" -size +3M -delete
