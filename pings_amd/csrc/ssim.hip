@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT, 3) void ssim_fwd_kernel(
       const float A2 = 2.f * sig12 + kC2;
       const float B1 = mu1_sq + mu2_sq + kC1;
       const float B2 = sig1 + sig2 + kC2;
-      const float inv_B1 = 1.f / B1, inv_B2 = 1.f / B2;
+      const float inv_B1 = __builtin_amdgcn_rcpf(B1), inv_B2 = __builtin_amdgcn_rcpf(B2);   // as ssim_fwd_sw_kernel
       const float m = (A1 * A2) * (inv_B1 * inv_B2);
       local += m;
       if (TRAIN) {
@@ -255,24 +255,26 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
   const bool up = alt && (band & 1);
   const int y_first = up ? ye + HALO - 1 : yb - HALO, y_step = up ? -1 : 1;      // input row of step t: y_first + t y_step
   const int r_first = up ? ye + 2 * HALO - 1 : yb - 2 * HALO;                    // output row finished at step t
-  const float* p1 = img1 + plane_off + (x_in ? x : 0);
-  const float* p2 = img2 + plane_off + (x_in ? x : 0);
+  // wave-uniform plane bases and 32-bit element offsets (one plane holds fewer than 2^31 pixels): the loads and stores
+  // take the scalar-base form and the per-row address is one 32-bit multiply-add, not a 64-bit chain per access
+  const float* const p1 = img1 + plane_off;
+  const float* const p2 = img2 + plane_off;
+  const int xc = x_in ? x : 0;
 
   constexpr int PFD = 4;     // input rows in flight ahead of the one being filtered
-  float ra[11], rb[11];      // slot t % 11 holds input row (yb - 5) + t; only PFD of them are live at a time
+  v2f rab[11];               // (img1, img2) of input row t in slot t % 11; only PFD of them are live at a time
   // pending output rows: slot (t + 5 - k) % 11 for the row that takes tap k of input row t; (mu1, mu2), (e11, e22), e12
   v2f accm[11], accs[11];
   float accx[11];
 #pragma unroll
   for (int i = 0; i < 11; ++i) {
-    ra[i] = 0.f; rb[i] = 0.f;
+    rab[i] = v2f{0.f, 0.f};
     if (i < PFD) {
       const int y = y_first + i * y_step;
       const bool in = x_in && y >= 0 && y < H;
-      const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
+      const int o = (y >= 0 && y < H ? y : 0) * W + xc;
       const float va = p1[o], vb = p2[o];
-      ra[i] = in ? va : 0.f;
-      rb[i] = in ? vb : 0.f;
+      rab[i] = v2f{in ? va : 0.f, in ? vb : 0.f};
     }
     accm[i] = v2f{0.f, 0.f}; accs[i] = v2f{0.f, 0.f}; accx[i] = 0.f;
   }
@@ -283,44 +285,40 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
     for (int i = 0; i < 11; ++i) {
       const int t = t0 + i;
       if (t < t_end) {                                   // wave-uniform
-        const float a0 = ra[i], b0 = rb[i];
+        const v2f c0 = rab[i];
         {   // the row PFD steps ahead
           const int y = y_first + (t + PFD) * y_step;
           const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
-          const size_t o = (size_t)(y >= 0 && y < H ? y : 0) * W;
+          const int o = (y >= 0 && y < H ? y : 0) * W + xc;
           const float va = p1[o], vb = p2[o];
-          ra[(i + PFD) % 11] = in ? va : 0.f;
-          rb[(i + PFD) % 11] = in ? vb : 0.f;
+          rab[(i + PFD) % 11] = v2f{in ? va : 0.f, in ? vb : 0.f};
         }
         // ---- horizontal: input columns x - 5 .. x + 5 of this row, tap k at column x - 5 + k
         // (the left neighbours first — tap 0 is the FARTHEST one — then the right ones as the taps reach them, so that at
-        // most six values per image are live)
-        float al[6], bl[6];
-        al[0] = a0; bl[0] = b0;
+        // most six pairs are live).  The two images travel as ONE register pair through the shift chains and the taps:
+        // formed per tap from two separate registers, the pair cost two moves each (35 of 234 vector instructions per row
+        // step in the first version of this kernel).
+        v2f l[6];
+        l[0] = c0;
 #pragma unroll
-        for (int j = 1; j <= 5; ++j) {
-          al[j] = dpp_wave<0x138>(al[j - 1]);            // lane l - j
-          bl[j] = dpp_wave<0x138>(bl[j - 1]);
-        }
+        for (int j = 1; j <= 5; ++j) l[j] = v2f{dpp_wave<0x138>(l[j - 1].x), dpp_wave<0x138>(l[j - 1].y)};   // lane l - j
         // packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32: two IEEE operations per instruction, the same roundings as the
-        // scalar forms, so the statistics stay bit-identical to the tile kernel's): (m1, m2) and (s11, s22) travel as pairs
+        // scalar forms): (m1, m2) and (s11, s22) travel as pairs
         v2f m12 = {0.f, 0.f}, s1122 = {0.f, 0.f};
         float s12 = 0.f;
-        auto tap = [&](float w, float a, float b) {
-          const v2f ab = {a, b};
+        auto tap = [&](float w, v2f ab) {
           const v2f wab = ab * w;
           m12 += wab;
           s1122 = __builtin_elementwise_fma(wab, ab, s1122);
-          s12 = fmaf(wab.x, b, s12);
+          s12 = fmaf(wab.x, ab.y, s12);
         };
-        tap(kWin[0], al[5], bl[5]); tap(kWin[1], al[4], bl[4]); tap(kWin[2], al[3], bl[3]);
-        tap(kWin[3], al[2], bl[2]); tap(kWin[4], al[1], bl[1]); tap(kWin[5], al[0], bl[0]);
-        float ar = a0, br = b0;
+        tap(kWin[0], l[5]); tap(kWin[1], l[4]); tap(kWin[2], l[3]);
+        tap(kWin[3], l[2]); tap(kWin[4], l[1]); tap(kWin[5], l[0]);
+        v2f rr = c0;
 #pragma unroll
         for (int k = 6; k < 11; ++k) {
-          ar = dpp_wave<0x130>(ar);                      // lane l + (k - 5)
-          br = dpp_wave<0x130>(br);
-          tap(kWin[k], ar, br);
+          rr = v2f{dpp_wave<0x130>(rr.x), dpp_wave<0x130>(rr.y)};          // lane l + (k - 5)
+          tap(kWin[k], rr);
         }
         // ---- vertical: this input row is tap k of output row (yb - 5 + t) + 5 - k
 #pragma unroll
@@ -343,17 +341,19 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
           const float A2 = 2.f * sig12 + kC2;
           const float B1 = mu1_sq + mu2_sq + kC1;
           const float B2 = sig1 + sig2 + kC2;
-          const float inv_B1 = 1.f / B1, inv_B2 = 1.f / B2;
+          // 1-ulp reciprocals (v_rcp_f32) instead of two IEEE divisions (ten instructions each under
+          // -fhip-fp32-correctly-rounded-divide-sqrt): B1, B2 >= C1, C2 > 0; 1.2e-7 relative, the tolerance is 1e-4
+          const float inv_B1 = __builtin_amdgcn_rcpf(B1), inv_B2 = __builtin_amdgcn_rcpf(B2);
           const float m = (A1 * A2) * (inv_B1 * inv_B2);
           local += m;
           if (TRAIN) {
             const float d_s1 = -m * inv_B2;
             const float d_s12 = 2.f * A1 * inv_B1 * inv_B2;
             const float d_mu1 = 2.f * mu2 * A2 * inv_B1 * inv_B2 - 2.f * mu1 * m * inv_B1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
-            const size_t o = plane_off + (size_t)r * W + x;
-            dm_dmu1[o] = d_mu1;
-            dm_dsigma1_sq[o] = d_s1;
-            dm_dsigma12[o] = d_s12;
+            const int o = r * W + x;
+            (dm_dmu1 + plane_off)[o] = d_mu1;
+            (dm_dsigma1_sq + plane_off)[o] = d_s1;
+            (dm_dsigma12 + plane_off)[o] = d_s12;
           }
         }
         accm[sl] = v2f{0.f, 0.f}; accs[sl] = v2f{0.f, 0.f}; accx[sl] = 0.f;   // the slot now belongs to output row r + 11
