@@ -282,6 +282,7 @@ struct MlpJobs {
   size_t per_block[MAX_JOBS];
   float *gW1[MAX_JOBS], *gb1[MAX_JOBS], *gW2[MAX_JOBS], *gb2[MAX_JOBS];
   int IN[MAX_JOBS], OUT[MAX_JOBS];
+  int wg0[MAX_JOBS + 1];   // backward: job g owns workgroups [wg0[g], wg0[g + 1]) of a 1-D grid (cost-proportional shares)
 };
 
 __global__ __launch_bounds__(256, 2) void mlp_fwd_wave_grouped_kernel(long long N, MlpJobs j,
@@ -608,7 +609,8 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
                                                   const float* __restrict__ b1, const float* __restrict__ W2,
                                                   float* __restrict__ gx, float* __restrict__ partials,
                                                   size_t per_block, float* __restrict__ sW1, float* __restrict__ sW2,
-                                                  float* __restrict__ sT, float* __restrict__ sXG) {
+                                                  float* __restrict__ sT, float* __restrict__ sXG, const int blk,
+                                                  const int nblk) {
   // LDS (declared once in mlp_bwd_wave_dispatch): sW1 = W1[hid][i] as [128][BW_LD], zero beyond IN; sW2 = W2[o][hid] as
   // [32][129], zero beyond OUT; sT = per wave H^T and gH^T as [4][2][32 * BW_LD] ([hid_local][row]); sXG = per wave the
   // double-buffered x and gY tiles [4][x0, x1, g0, g1][32 * BW_LD]
@@ -655,8 +657,8 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
   const float* const rdH = myH + r * BW_LD + 16 * h;          // + s                            (transpose: read)
   const float* const rdG = myG + r * BW_LD + 16 * h;
   const long long ntiles = (N + 31) / 32;
-  const long long nwaves = (long long)gridDim.x * 4;
-  const long long wave0 = (long long)blockIdx.x * 4 + wave;
+  const long long nwaves = (long long)nblk * 4;       // this decoder's share of the grid (mlp_bwd_wave_grouped_kernel)
+  const long long wave0 = (long long)blk * 4 + wave;
 
   // Row r of tile t: columns 16 h .. 16 h + 15 of x and of gY (zero beyond IN / OUT and beyond row N).  Every load is
   // issued whatever the row / column — the address is clamped into the array and the value masked afterwards with
@@ -851,7 +853,7 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
     }
   }
   __syncthreads();
-  float* P = partials + (size_t)blockIdx.x * per_block;
+  float* P = partials + (size_t)blk * per_block;
   const int nW1 = 128 * IN, nW2 = OUT * 128;
   for (int e = tid; e < nW1; e += 256) P[e] = sW1[(e / IN) * BW_LD + (e % IN)];
   for (int e = tid; e < nW2; e += 256) P[nW1 + e] = sW2[(e >> 7) * 129 + (e & 127)];
@@ -864,7 +866,7 @@ __device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int O
                                                       const float* __restrict__ gy, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, const float* __restrict__ W2,
                                                       float* __restrict__ gx, float* __restrict__ partials,
-                                                      size_t per_block) {
+                                                      size_t per_block, const int blk, const int nblk) {
   __shared__ float sW1[128 * BW_LD];
   __shared__ float sW2[32 * 129];
   __shared__ float sT[4 * 2 * 32 * BW_LD];
@@ -873,7 +875,7 @@ __device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int O
   const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
 #define PINGS_BWD_BODY(OH_, VX_, VG_) \
-  mlp_bwd_wave_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block, sW1, sW2, sT, sXG)
+  mlp_bwd_wave_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block, sW1, sW2, sT, sXG, blk, nblk)
 #define PINGS_BWD_CLASS(VX_)                          \
   do {                                                \
     if (!vecg) PINGS_BWD_BODY(16, VX_, false);        \
@@ -892,13 +894,17 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
                                                               const float* __restrict__ b1, const float* __restrict__ W2,
                                                               float* __restrict__ gx, float* __restrict__ partials,
                                                               size_t per_block) {
-  mlp_bwd_wave_dispatch(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block);
+  mlp_bwd_wave_dispatch(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block, (int)blockIdx.x, (int)gridDim.x);
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_grouped_kernel(long long N, MlpJobs j) {
-  const int g = blockIdx.y;
+// 1-D grid; decoder g owns workgroups [wg0[g], wg0[g + 1]): shares proportional to the decoders' MFMAs per tile (the
+// 32-wide rotation decoder issues 324 per tile, the 8-wide alpha decoder 276), so that they finish together — with
+// equal shares the launch lasted as long as its most expensive decoder (6 % more)
+__global__ __launch_bounds__(256, 1) void mlp_bwd_wave_grouped_kernel(long long N, MlpJobs j, int njobs) {
+  int g = 0;
+  while (g + 1 < njobs && (int)blockIdx.x >= j.wg0[g + 1]) ++g;
   mlp_bwd_wave_dispatch(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
-                        j.per_block[g]);
+                        j.per_block[g], (int)blockIdx.x - j.wg0[g], j.wg0[g + 1] - j.wg0[g]);
 }
 
 // ---------------------------------------------------------------- backward of the SDF decoder shape: HID = 64, OUT = 1
@@ -1108,8 +1114,9 @@ __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblock
   else gb2[e - nW1 - nW2 - HID] = s;
 }
 
-__global__ void mlp_reduce_grouped_kernel(MlpJobs j, int nblocks, int HID) {
+__global__ void mlp_reduce_grouped_kernel(MlpJobs j, int HID) {
   const int g = blockIdx.y;
+  const int nblocks = j.wg0[g + 1] - j.wg0[g];
   const size_t per_block = j.per_block[g];
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per_block) return;
@@ -1365,14 +1372,28 @@ PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, i
   }
   hipStream_t st = pings::as_stream(stream);
   pings::prof::Scope ps("mlp_bwd", st);
-  // one resident workgroup per CU over all jobs together (see the forward)
+  // one resident workgroup per CU over all jobs together (see the forward), split between the jobs in proportion to
+  // their MFMAs per tile: 4 x (17 + OH + 16 + 32), OH = k-steps of product B (mlp_bwd_wave_dispatch)
   const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
-  const long long cap = 256 / njobs;   // floor (see the forward)
-  const int grid_w = (int)(want < cap ? want : cap);
-  hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w, njobs), dim3(256), 0, st, (long long)N, J);
+  int cost[MAX_JOBS], total_cost = 0;
+  for (int g = 0; g < njobs; ++g) {
+    const bool vecg = (J.OUT[g] % 4 == 0) && ((reinterpret_cast<uintptr_t>(J.gy[g]) & 15) == 0);
+    const int oh = !vecg ? 16 : (J.OUT[g] == 24 ? 12 : (J.OUT[g] == 8 ? 4 : 16));
+    cost[g] = 17 + oh + 16 + 32;
+    total_cost += cost[g];
+  }
+  J.wg0[0] = 0;
+  for (int g = 0; g < njobs; ++g) {
+    long long share = (256LL * cost[g]) / total_cost;            // floor: never more than 256 workgroups in all
+    if (share < 1) share = 1;
+    if (share > want) share = want;
+    J.wg0[g + 1] = J.wg0[g] + (int)share;
+  }
+  const int grid_w = J.wg0[njobs];
+  hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, J, njobs);
   PINGS_LAUNCH_CHECK();
   hipLaunchKernelGGL(mlp_reduce_grouped_kernel, dim3((unsigned)pings::ceil_div<size_t>(max_pb, 256), njobs), dim3(256),
-                     0, st, J, grid_w, 128);
+                     0, st, J, 128);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }
