@@ -569,6 +569,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(Dims d, const float* __res
 // are added across the four waves in LDS (wave order) and written as one partial per workgroup, summed by
 // mlp_reduce_kernel in fixed order: bitwise reproducible.
 constexpr int BW_LD = 33;  // leading dimension of the private transpose tiles and of the W1 image
+constexpr int BW_LDS_FLOATS = 128 * BW_LD + 32 * 129 + 4 * 2 * 32 * BW_LD + 4 * 4 * 32 * BW_LD;   // mlp_bwd_wave_dispatch
+constexpr int BW_REGION = 128 * 32 + 32 * 129 + 160;   // one wave's weight-gradient region in the epilogue
+static_assert(4 * BW_REGION <= BW_LDS_FLOATS, "the four epilogue regions must fit the kernel's LDS");
 #ifdef PINGS_MLP_STATS
 __device__ unsigned long long g_mlp_stats[8];
 #endif
@@ -592,6 +595,18 @@ __device__ unsigned long long g_mlp_stats[8];
 #define MLP_SB_B MLP_SB_(1)
 #define MLP_SB_C MLP_SB_(2)
 #define MLP_SB_D MLP_SB_(3)
+// Scheduling GROUPS for the stretch between two transposes (PINGS_MLP_SGB = variant; 0 = none).  Left alone, the
+// compiler sinks each LDS operand read to just above its MFMA pair (ds_read2 -> s_waitcnt -> 2 MFMAs): a wave that is
+// alone on its SIMD then exposes (LDS latency - one MFMA) per pair.  A group barrier chain states the order by
+// instruction class only — reads first, then the matrix instructions — and leaves the rest to the scheduler.
+#ifndef PINGS_MLP_SGB
+#define PINGS_MLP_SGB 0
+#endif
+#define MLP_SGB_DSR 0x100
+#define MLP_SGB_DSW 0x200
+#define MLP_SGB_MFMA 0x008
+#define MLP_SGB_VALU 0x002
+#define MLP_SGB_VMEM_R 0x020
 
 // Round 4: the same five products, re-issued so that the matrix pipe does not wait for operands.
 //  * A PMC pass of round 3 put the pipe at 57 % busy; the ISA showed why: every LDS operand was fetched just in time
@@ -607,35 +622,26 @@ template <int OH, bool VECX, bool VECG>
 __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, const float* __restrict__ x,
                                                   const float* __restrict__ gy, const float* __restrict__ W1,
                                                   const float* __restrict__ b1, const float* __restrict__ W2,
-                                                  float* __restrict__ gx, float* __restrict__ partials,
-                                                  size_t per_block, float* __restrict__ sW1, float* __restrict__ sW2,
-                                                  float* __restrict__ sT, float* __restrict__ sXG, const int blk,
-                                                  const int nblk) {
+                                                  float* __restrict__ gx, float* __restrict__ sW1, float* __restrict__ sW2, float* __restrict__ sT,
+                                                  float* __restrict__ sXG, const int blk, const int nblk,
+                                                  f32x16 (&aW2T)[4], f32x16 (&aW1)[4], float (&aB1)[4], float& aB2) {
   // LDS (declared once in mlp_bwd_wave_dispatch): sW1 = W1[hid][i] as [128][BW_LD], zero beyond IN; sW2 = W2[o][hid] as
   // [32][129], zero beyond OUT; sT = per wave H^T and gH^T as [4][2][32 * BW_LD] ([hid_local][row]); sXG = per wave the
   // double-buffered x and gY tiles [4][x0, x1, g0, g1][32 * BW_LD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a scalar: the tile index, the tile's base addresses and the wave's LDS windows stay in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 128 * 32; e += 256) {
-    const int j = e >> 5, i = e & 31;
-    sW1[j * BW_LD + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
-  }
-  for (int e = tid; e < 32 * 128; e += 256) {
-    const int o = e >> 7, j = e & 127;
-    sW2[o * 129 + j] = o < OUT ? W2[(size_t)o * 128 + j] : 0.f;
-  }
-  float b1f[4];  // bias k-step of product A: (b1, 0) against (1, 0)
-#pragma unroll
-  for (int hb = 0; hb < 4; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
-  __syncthreads();
 
-  f32x16 aW2T[4], aW1[4];
-  float aB1[4] = {0.f, 0.f, 0.f, 0.f}, aB2 = 0.f;
 #pragma unroll
-  for (int hb = 0; hb < 4; ++hb)
+  for (int hb = 0; hb < 4; ++hb) {
+    aB1[hb] = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { aW2T[hb][q] = 0.f; aW1[hb][q] = 0.f; }
+  }
+  aB2 = 0.f;
 
+  float b1f[4];  // bias k-step of product A: (b1, 0) against (1, 0); loaded with the weight images below
   float* myH = sT + (wave * 2 + 0) * 32 * BW_LD;
   float* myG = sT + (wave * 2 + 1) * 32 * BW_LD;
   // the wave's private, double-buffered images of its tile of x and gY, [row][column] with leading dimension BW_LD
@@ -666,26 +672,35 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
   // fetch_rows only LOADS (raw values stay in flight in xd / gd for the whole tile); stage_rows masks them (integer and:
   // no select the compiler could turn back into a branch) and writes the LDS image.
   auto fetch_rows = [&](long long t, float (&xd)[16], float (&gd)[16]) {
-    const long long row = t * 32 + r;
-    const long long rowc = row < N ? row : N - 1;
-    const float* xr = x + (size_t)rowc * IN;
-    const float* gr = gy + (size_t)rowc * OUT;
+    // address = wave-uniform tile base (SGPR pair) + a 32-bit per-lane element offset.  (As 64-bit per-lane pointers
+    // the compiler kept ~25 loop-invariant address pairs, spilled them and re-read them from scratch at the top of
+    // every tile: 28 scratch loads in front of the fetch.)  The lane half goes through an opaque move so that the
+    // clamped column offsets are a handful of integer ops per tile instead of hoisted registers.
+    long long tb = t * 32;
+    if (tb > N - 1) tb = N - 1;                      // beyond the last tile: row N - 1 again, never used
+    const long long below = N - 1 - tb;              // rows of the array after the tile's first one
+    const int rl = below < 31 ? (r < (int)below ? r : (int)below) : r;
+    int hh = h;
+    __asm__ volatile("" : "+v"(hh));
+    const float* xb = x + (size_t)tb * IN;
+    const float* gb = gy + (size_t)tb * OUT;
+    const uint32_t xro = (uint32_t)(rl * IN), gro = (uint32_t)(rl * OUT);   // unsigned: the saddr + 32-bit voffset form
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      const int k = 16 * h + 4 * q4;
+      const int k = 16 * hh + 4 * q4;
       if (VECX) {    // IN a multiple of four, 16-byte aligned rows
-        const float4 v = *reinterpret_cast<const float4*>(xr + (k < IN ? k : 0));
+        const float4 v = *reinterpret_cast<const float4*>(xb + (xro + (uint32_t)(k < IN ? k : 0)));
         xd[4 * q4] = v.x; xd[4 * q4 + 1] = v.y; xd[4 * q4 + 2] = v.z; xd[4 * q4 + 3] = v.w;
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = xr[k + u < IN ? k + u : 0];
+        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = xb[xro + (uint32_t)(k + u < IN ? k + u : 0)];
       }
       if (VECG) {
-        const float4 u4 = *reinterpret_cast<const float4*>(gr + (k < OUT ? k : 0));
+        const float4 u4 = *reinterpret_cast<const float4*>(gb + (gro + (uint32_t)(k < OUT ? k : 0)));
         gd[4 * q4] = u4.x; gd[4 * q4 + 1] = u4.y; gd[4 * q4 + 2] = u4.z; gd[4 * q4 + 3] = u4.w;
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = gr[k + u < OUT ? k + u : 0];
+        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = gb[gro + (uint32_t)(k + u < OUT ? k + u : 0)];
       }
     }
   };
@@ -717,10 +732,35 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
 #else
 #define MLP_TICK(k_) do { } while (0)
 #endif
+  // row views (B operands of products A / B) of the tile about to be processed: read from the staged image at the END
+  // of the previous tile, under its last weight-gradient products, so that a tile starts with its MFMAs
+  float xf[16], gyf[OH];
+  auto read_rows = [&](int b) {
+    const float* bxr = myX + b * 32 * BW_LD + r * BW_LD + 16 * h;
+    const float* bgr = myGY + b * 32 * BW_LD + r * BW_LD + o0;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) xf[s2] = bxr[s2];
+#pragma unroll
+    for (int s2 = 0; s2 < OH; ++s2) gyf[s2] = bgr[s2];
+  };
   float xn[16], gn[16];
   int buf = 0;
   fetch_rows(wave0 < ntiles ? wave0 : 0, xn, gn);
+  // the weight images are staged under the first tile's fetch
+  for (int e = tid; e < 128 * 32; e += 256) {
+    const int j = e >> 5, i = e & 31;
+    sW1[j * BW_LD + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
+  }
+  for (int e = tid; e < 32 * 128; e += 256) {
+    const int o = e >> 7, j = e & 127;
+    sW2[o * 129 + j] = o < OUT ? W2[(size_t)o * 128 + j] : 0.f;
+  }
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
+  __syncthreads();
   stage_rows(0, wave0 < ntiles ? wave0 : 0, xn, gn);
+  MLP_WB_T;
+  read_rows(0);
   load_AB(0);
   const float one = h == 0 ? 1.f : 0.f;
   MLP_TICK(0);   // prologue
@@ -728,21 +768,15 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
     // the next tile's rows: in flight for the whole of this tile, staged into the other LDS buffer at its end
     // (beyond the last tile the clamped addresses re-read row N - 1 and the values are never used)
     fetch_rows(t + nwaves, xn, gn);
-    MLP_WB_T;
-    float xf[16], gyf[OH], xcol[16], gycol[16];
+    float xcol[16], gycol[16];     // column views (B operands of the weight-gradient products): first used in product D
     {
-      const float* bxr = myX + buf * 32 * BW_LD + r * BW_LD + 16 * h;     // row view
-      const float* bxc = myX + buf * 32 * BW_LD + 16 * h * BW_LD + r;     // column view
-      const float* bgr = myGY + buf * 32 * BW_LD + r * BW_LD + o0;
+      const float* bxc = myX + buf * 32 * BW_LD + 16 * h * BW_LD + r;
       const float* bgc = myGY + buf * 32 * BW_LD + 16 * h * BW_LD + r;
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
-        xf[s2] = bxr[s2];
         xcol[s2] = bxc[s2 * BW_LD];
         gycol[s2] = bgc[s2 * BW_LD];
       }
-#pragma unroll
-      for (int s2 = 0; s2 < OH; ++s2) gyf[s2] = bgr[s2];
     }
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) aB2 += gycol[s2];
@@ -776,6 +810,8 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         wrH[((q & 3) + 8 * (q >> 2)) * BW_LD] = pre[q];
         wrG[((q & 3) + 8 * (q >> 2)) * BW_LD] = gH[q];
       }
+      // last hidden block: the next tile's rows (in flight since the top of this tile) go into the other image
+      if (hb == 3) stage_rows(buf ^ 1, t + nwaves, xn, gn);
       MLP_WB_R;
       float aH[16], aG[16];
 #pragma unroll
@@ -784,11 +820,44 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
         aG[s2] = rdG[s2];
       }
       MLP_SB_C;
+#if PINGS_MLP_SGB == 1
+      // the transposed operands, then product C, then every other LDS read of the stretch, then the rest of the MFMAs
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 64, 0);
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 96, 0);
+#elif PINGS_MLP_SGB == 2
+      // as 1, with the second batch of reads spread under product C (four MFMAs, eight reads, ...)
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 16, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 4; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 12, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 96, 0);
+#elif PINGS_MLP_SGB == 3
+      // every MFMA of the stretch preceded by one LDS read while there are any
+#pragma unroll
+      for (int g_ = 0; g_ < 64; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 1, 0);
+      }
+#elif PINGS_MLP_SGB == 4
+      // reads two at a time, one MFMA between the pairs
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 8, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 40; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(MLP_SGB_DSR, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(MLP_SGB_MFMA, 96, 0);
+#endif
 #pragma unroll
       for (int q = 0; q < 16; ++q) gxacc = mfma(opC[q], gH[q], gxacc);   // (computed even when gx is null: no branch)
       MLP_TICK(4);   // transposes + product C issued
       // ---- the weight-gradient products; meanwhile the operands of the next hidden block's A and B
       load_AB((hb + 1) & 3);
+      if (hb == 3) read_rows(buf ^ 1);
       MLP_SB_D;
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
@@ -798,9 +867,8 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
       }
       MLP_TICK(5);   // products D issued
     }
-    stage_rows(buf ^ 1, t + nwaves, xn, gn);
     buf ^= 1;
-    MLP_TICK(6);   // next tile staged
+    MLP_TICK(6);
     if (gx) {
       const long long row = t * 32 + r;
       if (row < N) {
@@ -829,36 +897,51 @@ __device__ __forceinline__ void mlp_bwd_wave_body(long long N, int IN, int OUT, 
   if (lane == 0)
     for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_mlp_stats[k_], st_t[k_]);
 #endif
-  // ---- the workgroup's partial weight gradients: the four waves add theirs in wave order into the (now dead)
-  // weight images, which already have the conflict-free layouts [hid][33] and [o][129]; one partial per workgroup
-  float* sB = sT;  // gb1[128], gb2[32]
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
+}
+
+// The workgroup's partial weight gradients (after mlp_bwd_wave_body; its own function so that the body's LDS pointers,
+// which promise not to alias each other, are out of scope when the whole array is re-carved).  Every wave writes its
+// accumulators into its OWN region of the (now dead) LDS at once, then all 256 threads add the four regions in wave
+// order and write the partial in the global layout.  (Round 3 let the waves take turns adding into one image: four
+// serial rounds and five barriers, ~5 us of the launch's ~35 us of fixed cost.)  Region: gW1 as [hid][32] (lane = i),
+// gW2 as [o][129] (lane = o), gb1, gb2.
+__device__ __forceinline__ void mlp_bwd_wave_epilogue(int IN, int OUT, float* __restrict__ partials, size_t per_block,
+                                                      float* __restrict__ sAll, const int blk, const f32x16 (&aW2T)[4],
+                                                      const f32x16 (&aW1)[4], const float (&aB1)[4], const float aB2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  __syncthreads();
+  {
+    float* R = sAll + wave * BW_REGION;
+    float* rW1 = R, *rW2 = R + 128 * 32, *rB = R + 128 * 32 + 32 * 129;
 #pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {
+    for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int hid = hb * 32 + rowmap(q, h);
-          float* d2 = &sW2[r * 129 + hid];     // lane = o
-          float* d1 = &sW1[hid * BW_LD + r];   // lane = i
-          if (w == 0) { *d2 = aW2T[hb][q]; *d1 = aW1[hb][q]; }
-          else { *d2 += aW2T[hb][q]; *d1 += aW1[hb][q]; }
-        }
-        const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);  // the two row halves of hidden unit hb*32 + r
-        if (h == 0) { if (w == 0) sB[hb * 32 + r] = v; else sB[hb * 32 + r] += v; }
+      for (int q = 0; q < 16; ++q) {
+        const int hid = hb * 32 + rowmap(q, h);
+        rW2[r * 129 + hid] = aW2T[hb][q];
+        rW1[hid * 32 + r] = aW1[hb][q];
       }
-      const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
-      if (h == 0) { if (w == 0) sB[128 + r] = v2; else sB[128 + r] += v2; }
+      const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);  // the two row halves of hidden unit hb*32 + r
+      if (h == 0) rB[hb * 32 + r] = v;
     }
+    const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
+    if (h == 0) rB[128 + r] = v2;
   }
   __syncthreads();
   float* P = partials + (size_t)blk * per_block;
   const int nW1 = 128 * IN, nW2 = OUT * 128;
-  for (int e = tid; e < nW1; e += 256) P[e] = sW1[(e / IN) * BW_LD + (e % IN)];
-  for (int e = tid; e < nW2; e += 256) P[nW1 + e] = sW2[(e >> 7) * 129 + (e & 127)];
-  if (tid < 128) P[nW1 + nW2 + tid] = sB[tid];
-  if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sB[128 + tid];
+  auto sum4 = [&](int off) {
+    return ((sAll[off] + sAll[BW_REGION + off]) + sAll[2 * BW_REGION + off]) + sAll[3 * BW_REGION + off];
+  };
+  {
+    const int i = tid & 31;
+    if (i < IN)
+      for (int j = tid >> 5; j < 128; j += 8) P[j * IN + i] = sum4(j * 32 + i);
+  }
+  for (int e = tid; e < nW2; e += 256) P[nW1 + e] = sum4(128 * 32 + (e >> 7) * 129 + (e & 127));
+  if (tid < 128) P[nW1 + nW2 + tid] = sum4(128 * 32 + 32 * 129 + tid);
+  if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sum4(128 * 32 + 32 * 129 + 128 + tid);
 }
 
 // one instantiation per output class (the B product's k-steps are compile-time); the choice is uniform per workgroup
@@ -867,15 +950,18 @@ __device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int O
                                                       const float* __restrict__ b1, const float* __restrict__ W2,
                                                       float* __restrict__ gx, float* __restrict__ partials,
                                                       size_t per_block, const int blk, const int nblk) {
-  __shared__ float sW1[128 * BW_LD];
-  __shared__ float sW2[32 * 129];
-  __shared__ float sT[4 * 2 * 32 * BW_LD];
-  __shared__ float sXG[4 * 4 * 32 * BW_LD];     // 135 KB in all: one workgroup per CU, as the registers dictate anyway
+  // one array (the epilogue re-carves it into four per-wave regions): W1 image, W2 image, transposes, x / gY tiles.
+  // 135 KB in all: one workgroup per CU, as the registers dictate anyway
+  __shared__ float sAll[BW_LDS_FLOATS];
+  float* const sW1 = sAll;
+  float* const sW2 = sW1 + 128 * BW_LD;
+  float* const sT = sW2 + 32 * 129;
+  float* const sXG = sT + 4 * 2 * 32 * BW_LD;
   // 16-byte row loads where the row length and the base allow (the colour decoder's 19 inputs: scalar loads of x)
   const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
 #define PINGS_BWD_BODY(OH_, VX_, VG_) \
-  mlp_bwd_wave_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, partials, per_block, sW1, sW2, sT, sXG, blk, nblk)
+  mlp_bwd_wave_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, sW1, sW2, sT, sXG, blk, nblk, aW2T, aW1, aB1, aB2)
 #define PINGS_BWD_CLASS(VX_)                          \
   do {                                                \
     if (!vecg) PINGS_BWD_BODY(16, VX_, false);        \
@@ -883,10 +969,13 @@ __device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int O
     else if (OUT == 8) PINGS_BWD_BODY(4, VX_, true);  \
     else PINGS_BWD_BODY(16, VX_, true);               \
   } while (0)
+  f32x16 aW2T[4], aW1[4];   // the wave's weight-gradient accumulators: 128 registers for the whole launch
+  float aB1[4], aB2;
   if (vecx) PINGS_BWD_CLASS(true);
   else PINGS_BWD_CLASS(false);
 #undef PINGS_BWD_CLASS
 #undef PINGS_BWD_BODY
+  mlp_bwd_wave_epilogue(IN, OUT, partials, per_block, sAll, blk, aW2T, aW1, aB1, aB2);
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
@@ -1375,20 +1464,30 @@ PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, i
   // one resident workgroup per CU over all jobs together (see the forward), split between the jobs in proportion to
   // their MFMAs per tile: 4 x (17 + OH + 16 + 32), OH = k-steps of product B (mlp_bwd_wave_dispatch)
   const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
-  int cost[MAX_JOBS], total_cost = 0;
+  int cost[MAX_JOBS];
   for (int g = 0; g < njobs; ++g) {
     const bool vecg = (J.OUT[g] % 4 == 0) && ((reinterpret_cast<uintptr_t>(J.gy[g]) & 15) == 0);
     const int oh = !vecg ? 16 : (J.OUT[g] == 24 ? 12 : (J.OUT[g] == 8 ? 4 : 16));
     cost[g] = 17 + oh + 16 + 32;
-    total_cost += cost[g];
+  }
+  // 256 workgroups (one per CU) over the jobs so that the LAST wave finishes as early as possible: a job with w
+  // workgroups needs ceil(ntiles / 4w) rounds of cost[g] MFMAs.  Greedy on the maximum (one more workgroup to the job
+  // that finishes last) is optimal for a minimum over non-increasing step functions.  Shares merely proportional to
+  // the costs left 5.9 % on the table at 125k points: 3907 tiles over 54 x 4 waves are 18.09 -> 19 rounds.
+  int share[MAX_JOBS];
+  for (int g = 0; g < njobs; ++g) share[g] = 1;
+  for (int left = 256 - njobs; left > 0; --left) {
+    int worst = -1;
+    long long worst_t = -1;
+    for (int g = 0; g < njobs; ++g) {
+      const long long t_g = ((ntiles + 4LL * share[g] - 1) / (4LL * share[g])) * cost[g];
+      if (t_g > worst_t) { worst_t = t_g; worst = g; }
+    }
+    if (share[worst] >= want) break;      // one tile per wave already: more workgroups would idle
+    ++share[worst];
   }
   J.wg0[0] = 0;
-  for (int g = 0; g < njobs; ++g) {
-    long long share = (256LL * cost[g]) / total_cost;            // floor: never more than 256 workgroups in all
-    if (share < 1) share = 1;
-    if (share > want) share = want;
-    J.wg0[g + 1] = J.wg0[g] + (int)share;
-  }
+  for (int g = 0; g < njobs; ++g) J.wg0[g + 1] = J.wg0[g] + share[g];
   const int grid_w = J.wg0[njobs];
   hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, J, njobs);
   PINGS_LAUNCH_CHECK();
