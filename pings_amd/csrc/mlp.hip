@@ -574,6 +574,7 @@ constexpr int BW_REGION = 128 * 32 + 32 * 129 + 160;   // one wave's weight-grad
 static_assert(4 * BW_REGION <= BW_LDS_FLOATS, "the four epilogue regions must fit the kernel's LDS");
 #ifdef PINGS_MLP_STATS
 __device__ unsigned long long g_mlp_stats[8];
+__device__ unsigned long long g_mlp_clock[2];   // shader-clock cycles and 100 MHz real-time ticks of one workgroup's life
 #endif
 // Optional scheduling barriers of mlp_bwd_wave_body (bit k of PINGS_MLP_SB = barrier k; A/B builds, tools/mlp_sb_ab.sh):
 // A, C, D pin the operand reads of the NEXT product above the MFMAs of the current one, B the mask below the products
@@ -978,6 +979,315 @@ __device__ __forceinline__ void mlp_bwd_wave_dispatch(long long N, int IN, int O
   mlp_bwd_wave_epilogue(IN, OUT, partials, per_block, sAll, blk, aW2T, aW1, aB1, aB2);
 }
 
+// ---------------------------------------------------------------- backward, TWO waves per SIMD (round 4)
+// mlp_bwd_wave_body keeps one wave per SIMD (its 128 accumulator registers + every operand read one product ahead need
+// ~430 of the 512 registers), and a wave that is alone on its SIMD pays every latency it cannot schedule around: the
+// launch runs its MFMAs at 72 % of the pipe in steady state where the bare MFMA stream of one wave reaches 88 %
+// (tools/dec_scale.py with timing-only ablation builds; profiles/mfma_calib.hip: one wave per SIMD 140-148 TFLOP/s,
+// two waves 154).  This body fits a wave into 256 registers so that EIGHT waves share a CU: the operands are read
+// from LDS where they are used (the other wave of the SIMD covers the round trip), H^T and gH^T take turns in ONE
+// private transpose tile (the two weight-gradient products run one after the other), the tile of x / gY is single-
+// buffered (the next tile's rows are fetched under the last product and staged after it).  Same
+// products, same k orders, same accumulation order per accumulator as mlp_bwd_wave_body: bit-identical partials per
+// wave; a workgroup's partial adds eight waves instead of four.
+template <int OH, bool VECX, bool VECG>
+__device__ __forceinline__ void mlp_bwd_wave2_body(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                   const float* __restrict__ gy, const float* __restrict__ W1,
+                                                   const float* __restrict__ b1, const float* __restrict__ W2,
+                                                   float* __restrict__ gx, float* __restrict__ sW1,
+                                                   float* __restrict__ sW2, float* __restrict__ sP, const int blk,
+                                                   const int nblk, f32x16 (&aW2T)[4], f32x16 (&aW1)[4],
+                                                   float (&aB1)[4], float& aB2) {
+  // LDS: sW1 = W1[hid][i] as [128][BW_LD]; sW2 = W2^T[hid][o] as [128][BW_LD] (the k-steps of product B are then
+  // neighbours in memory, like product A's); sP = per wave [T, X, G][32 * BW_LD]:
+  // T = the transpose tile ([hid_local][row]), X / G = this tile's rows of x and gY ([row][column])
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    aB1[hb] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { aW2T[hb][q] = 0.f; aW1[hb][q] = 0.f; }
+  }
+  aB2 = 0.f;
+  float* const myT = sP + (wave * 3 + 0) * 32 * BW_LD;
+  float* const myX = sP + (wave * 3 + 1) * 32 * BW_LD;
+  float* const myG = sP + (wave * 3 + 2) * 32 * BW_LD;
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)nblk * 8;
+  const long long wave0 = (long long)blk * 8 + wave;
+
+  auto fetch_rows = [&](long long t, float (&xd)[16], float (&gd)[16]) {   // as in mlp_bwd_wave_body
+    long long tb = t * 32;
+    if (tb > N - 1) tb = N - 1;
+    // (opaque scalar: without it the compiler turns every load's address into its own 64-bit per-lane induction
+    // variable across the tile loop — 20 register pairs that a 256-register wave does not have)
+    __asm__ volatile("" : "+s"(tb));
+    const long long below = N - 1 - tb;
+    const int rl = below < 31 ? (r < (int)below ? r : (int)below) : r;
+    int hh = h;
+    __asm__ volatile("" : "+v"(hh));
+    const float* xb = x + (size_t)tb * IN;
+    const float* gb = gy + (size_t)tb * OUT;
+    const uint32_t xro = (uint32_t)(rl * IN), gro = (uint32_t)(rl * OUT);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int k = 16 * hh + 4 * q4;
+      if (VECX) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (xro + (uint32_t)(k < IN ? k : 0)));
+        xd[4 * q4] = v.x; xd[4 * q4 + 1] = v.y; xd[4 * q4 + 2] = v.z; xd[4 * q4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xd[4 * q4 + u] = xb[xro + (uint32_t)(k + u < IN ? k + u : 0)];
+      }
+      if (VECG) {
+        const float4 u4 = *reinterpret_cast<const float4*>(gb + (gro + (uint32_t)(k < OUT ? k : 0)));
+        gd[4 * q4] = u4.x; gd[4 * q4 + 1] = u4.y; gd[4 * q4 + 2] = u4.z; gd[4 * q4 + 3] = u4.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gd[4 * q4 + u] = gb[gro + (uint32_t)(k + u < OUT ? k + u : 0)];
+      }
+    }
+  };
+  auto stage_rows = [&](long long t, const float (&xd)[16], const float (&gd)[16]) {
+    const uint32_t live = (t * 32 + r) < N ? 0xFFFFFFFFu : 0u;
+    int rr = r, hh = h;
+    __asm__ volatile("" : "+v"(rr), "+v"(hh));
+    float* dx = myX + rr * BW_LD + 16 * hh;
+    float* dg = myG + rr * BW_LD + 16 * hh;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int c = 16 * hh + s2;
+      dx[s2] = __uint_as_float(__float_as_uint(xd[s2]) & (c < IN ? live : 0u));
+      dg[s2] = __uint_as_float(__float_as_uint(gd[s2]) & (c < OUT ? live : 0u));
+    }
+  };
+
+  float xn[16], gn[16];
+  fetch_rows(wave0 < ntiles ? wave0 : 0, xn, gn);
+  // the weight images are staged under the first tile's fetch
+  for (int e = tid; e < 128 * 32; e += 512) {
+    const int j = e >> 5, i = e & 31;
+    sW1[j * BW_LD + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
+  }
+  for (int e = tid; e < 32 * 128; e += 512) {
+    const int o = e >> 7, j = e & 127;
+    sW2[j * BW_LD + o] = o < OUT ? W2[(size_t)o * 128 + j] : 0.f;
+  }
+  float b1f[4];  // bias k-step of product A: (b1, 0) against (1, 0)
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
+  stage_rows(wave0 < ntiles ? wave0 : 0, xn, gn);
+  __syncthreads();
+  const float one = h == 0 ? 1.f : 0.f;
+
+  // Every LDS address is formed where it is used from the lane's (r, h), which go through an opaque move first: left to
+  // itself the compiler hoists ~60 loop-invariant address registers out of the tile loop, or keeps a hidden block's
+  // nine bases alive through all of its phases, and spills them (189 dwords of scratch in the first build, reloaded
+  // one by one in front of the reads).  A handful of integer ops per phase instead.
+#define MLP_RH int rr = r, hh = h; __asm__ volatile("" : "+v"(rr), "+v"(hh))
+  for (long long t = wave0; t < ntiles; t += nwaves) {
+    f32x16 gxacc = {0};
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      // ---- A: pre^T = W1_hb x^T + b1;  B: gH^T = W2_hb^T gY^T
+      f32x16 pre = {0}, gH = {0};
+      {
+        MLP_RH;
+        const float* const baseA = sW1 + (hb * 32 + rr) * BW_LD + 16 * hh;   // + s
+        const float* const baseB = sW2 + (hb * 32 + rr) * BW_LD + hh * OH;   // + s
+        const float* const xrow = myX + rr * BW_LD + 16 * hh;                // + s
+        const float* const grow = myG + rr * BW_LD + hh * OH;                // + s
+#pragma unroll
+        for (int s2 = 0; s2 < 17; ++s2) {
+          pre = mfma(s2 < 16 ? baseA[s2] : b1f[hb], s2 < 16 ? xrow[s2] : one, pre);
+          if (s2 < OH) gH = mfma(baseB[s2], grow[s2], gH);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const bool on = pre[q] > 0.f;
+        gH[q] = on ? gH[q] : 0.f;
+        pre[q] = on ? pre[q] : 0.f;
+      }
+      // ---- H^T through the transpose tile
+      MLP_WB_W;
+      {
+        MLP_RH;
+        float* const wrT = myT + 4 * hh * BW_LD + rr;                        // + rm(q) * BW_LD
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wrT[((q & 3) + 8 * (q >> 2)) * BW_LD] = pre[q];
+      }
+      MLP_WB_R;
+      // ---- C: gX^T += W1_hb^T gH^T (operands in registers / the weight image: covers the transpose's round trip)
+      {
+        MLP_RH;
+        const float* const baseC = sW1 + (hb * 32 + 4 * hh) * BW_LD + rr;    // + rm(q) * BW_LD
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gxacc = mfma(baseC[((q & 3) + 8 * (q >> 2)) * BW_LD], gH[q], gxacc);
+      }
+      // ---- D1: gW2^T_hb += H^T gY
+      {
+        MLP_RH;
+        const float* const rdT = myT + rr * BW_LD + 16 * hh;                 // + s
+        const float* const gcolp = myG + 16 * hh * BW_LD + rr;               // + s * BW_LD
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) aW2T[hb] = mfma(rdT[s2], gcolp[s2 * BW_LD], aW2T[hb]);
+      }
+      // ---- gH^T takes the tile over
+      MLP_WB_W;
+      {
+        MLP_RH;
+        float* const wrT = myT + 4 * hh * BW_LD + rr;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wrT[((q & 3) + 8 * (q >> 2)) * BW_LD] = gH[q];
+      }
+      MLP_WB_R;
+      // the next tile's rows: fetched into the 32 registers that pre / gH have just vacated (a wave has 256), in flight
+      // under the last product and the gX store; what is left of the latency is the SIMD's other wave's to cover
+      if (hb == 3) fetch_rows(t + nwaves, xn, gn);
+      // ---- D2: gW1_hb += gH^T x, gb1 from the transposed fragments (the add is pinned where the fragment arrives:
+      // scheduled freely, the sixteen fragments of every hidden block were kept for a packed add at the tile's end)
+      {
+        MLP_RH;
+        const float* const rdT = myT + rr * BW_LD + 16 * hh;
+        const float* const xcolp = myX + 16 * hh * BW_LD + rr;               // + s * BW_LD
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const float aG = rdT[s2];
+          __asm__ volatile("v_add_f32 %0, %0, %1" : "+v"(aB1[hb]) : "v"(aG));
+          aW1[hb] = mfma(aG, xcolp[s2 * BW_LD], aW1[hb]);
+        }
+      }
+    }
+    {
+      MLP_RH;
+      const float* const gcolp = myG + 16 * hh * BW_LD + rr;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) aB2 += gcolp[s2 * BW_LD];
+    }
+    if (gx) {
+      long long t32 = t * 32;
+      __asm__ volatile("" : "+s"(t32));          // scalar tile base + 32-bit lane offset, as in fetch_rows
+      const long long row = t32 + r;
+      if (row < N) {
+        float* dst = gx + (size_t)t32 * IN + (uint32_t)(r * IN);
+        if (IN % 4 == 0 && ((reinterpret_cast<uintptr_t>(gx) & 15) == 0)) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int i = 8 * gq + 4 * h;
+            if (i < IN)
+              *reinterpret_cast<float4*>(dst + i) =
+                  make_float4(gxacc[4 * gq], gxacc[4 * gq + 1], gxacc[4 * gq + 2], gxacc[4 * gq + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int i = rowmap(q, h);
+            if (i < IN) dst[i] = gxacc[q];
+          }
+        }
+      }
+    }
+    // ---- the next tile's rows replace this one's (every read of X / G above is complete: same wave, program order)
+    MLP_WB_W;
+    stage_rows(t + nwaves, xn, gn);
+    MLP_WB_R;
+  }
+}
+#undef MLP_RH
+
+// eight waves: waves 0-3 store their accumulators into the four regions, waves 4-7 add theirs on top, then all
+// threads add the four regions in order: ((w0 + w4) + (w1 + w5)) + (w2 + w6)) + (w3 + w7)
+__device__ __forceinline__ void mlp_bwd_wave2_epilogue(int IN, int OUT, float* __restrict__ partials, size_t per_block,
+                                                       float* __restrict__ sAll, const int blk, const f32x16 (&aW2T)[4],
+                                                       const f32x16 (&aW1)[4], const float (&aB1)[4], const float aB2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();
+    if ((wave >> 2) == round) {
+      float* R = sAll + (wave & 3) * BW_REGION;
+      float* rW1 = R, *rW2 = R + 128 * 32, *rB = R + 128 * 32 + 32 * 129;
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int hid = hb * 32 + rowmap(q, h);
+          if (round == 0) { rW2[r * 129 + hid] = aW2T[hb][q]; rW1[hid * 32 + r] = aW1[hb][q]; }
+          else { rW2[r * 129 + hid] += aW2T[hb][q]; rW1[hid * 32 + r] += aW1[hb][q]; }
+        }
+        const float v = aB1[hb] + __shfl_xor(aB1[hb], 32, 64);
+        if (h == 0) { if (round == 0) rB[hb * 32 + r] = v; else rB[hb * 32 + r] += v; }
+      }
+      const float v2 = aB2 + __shfl_xor(aB2, 32, 64);
+      if (h == 0) { if (round == 0) rB[128 + r] = v2; else rB[128 + r] += v2; }
+    }
+  }
+  __syncthreads();
+  float* P = partials + (size_t)blk * per_block;
+  const int nW1 = 128 * IN, nW2 = OUT * 128;
+  auto sum4 = [&](int off) {
+    return ((sAll[off] + sAll[BW_REGION + off]) + sAll[2 * BW_REGION + off]) + sAll[3 * BW_REGION + off];
+  };
+  {
+    const int i = tid & 31;
+    if (i < IN)
+      for (int j = tid >> 5; j < 128; j += 16) P[j * IN + i] = sum4(j * 32 + i);
+  }
+  for (int e = tid; e < nW2; e += 512) P[nW1 + e] = sum4(128 * 32 + (e >> 7) * 129 + (e & 127));
+  if (tid < 128) P[nW1 + nW2 + tid] = sum4(128 * 32 + 32 * 129 + tid);
+  if (tid < OUT) P[nW1 + nW2 + 128 + tid] = sum4(128 * 32 + 32 * 129 + 128 + tid);
+}
+
+__device__ __forceinline__ void mlp_bwd_wave2_dispatch(long long N, int IN, int OUT, const float* __restrict__ x,
+                                                       const float* __restrict__ gy, const float* __restrict__ W1,
+                                                       const float* __restrict__ b1, const float* __restrict__ W2,
+                                                       float* __restrict__ gx, float* __restrict__ partials,
+                                                       size_t per_block, const int blk, const int nblk) {
+  constexpr int LDS2 = 2 * 128 * BW_LD + 8 * 3 * 32 * BW_LD;   // W1 image, W2^T image, 8 waves x [T, X, G] tiles: 135 KB
+  static_assert(4 * BW_REGION <= LDS2, "the four epilogue regions must fit the kernel's LDS");
+  __shared__ float sAll[LDS2];
+  float* const sW1 = sAll;
+  float* const sW2 = sW1 + 128 * BW_LD;
+  float* const sP = sW2 + 128 * BW_LD;
+  const bool vecx = (IN % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool vecg = (OUT % 4 == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+  f32x16 aW2T[4], aW1[4];
+  float aB1[4], aB2;
+#define PINGS_BWD2_BODY(OH_, VX_, VG_) \
+  mlp_bwd_wave2_body<OH_, VX_, VG_>(N, IN, OUT, x, gy, W1, b1, W2, gx, sW1, sW2, sP, blk, nblk, aW2T, aW1, aB1, aB2)
+#define PINGS_BWD2_CLASS(VX_)                           \
+  do {                                                 \
+    if (!vecg) PINGS_BWD2_BODY(16, VX_, false);         \
+    else if (OUT == 24) PINGS_BWD2_BODY(12, VX_, true); \
+    else if (OUT == 8) PINGS_BWD2_BODY(4, VX_, true);   \
+    else PINGS_BWD2_BODY(16, VX_, true);                \
+  } while (0)
+  if (vecx) PINGS_BWD2_CLASS(true);
+  else PINGS_BWD2_CLASS(false);
+#undef PINGS_BWD2_CLASS
+#undef PINGS_BWD2_BODY
+  mlp_bwd_wave2_epilogue(IN, OUT, partials, per_block, sAll, blk, aW2T, aW1, aB1, aB2);
+}
+
+__global__ __launch_bounds__(512) void mlp_bwd_wave2_grouped_kernel(long long N, MlpJobs j, int njobs) {
+#ifdef PINGS_MLP_STATS
+  const unsigned long long c0_ = __builtin_readcyclecounter(), w0_ = wall_clock64();
+#endif
+  int g = 0;
+  while (g + 1 < njobs && (int)blockIdx.x >= j.wg0[g + 1]) ++g;
+  mlp_bwd_wave2_dispatch(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
+                         j.per_block[g], (int)blockIdx.x - j.wg0[g], j.wg0[g + 1] - j.wg0[g]);
+#ifdef PINGS_MLP_STATS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_mlp_clock[0] = __builtin_readcyclecounter() - c0_;
+    g_mlp_clock[1] = wall_clock64() - w0_;
+  }
+#endif
+}
+
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int IN, int OUT, const float* __restrict__ x,
                                                               const float* __restrict__ gy, const float* __restrict__ W1,
                                                               const float* __restrict__ b1, const float* __restrict__ W2,
@@ -990,10 +1300,19 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_kernel(long long N, int I
 // 32-wide rotation decoder issues 324 per tile, the 8-wide alpha decoder 276), so that they finish together — with
 // equal shares the launch lasted as long as its most expensive decoder (6 % more)
 __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_grouped_kernel(long long N, MlpJobs j, int njobs) {
+#ifdef PINGS_MLP_STATS
+  const unsigned long long c0_ = __builtin_readcyclecounter(), w0_ = wall_clock64();
+#endif
   int g = 0;
   while (g + 1 < njobs && (int)blockIdx.x >= j.wg0[g + 1]) ++g;
   mlp_bwd_wave_dispatch(N, j.IN[g], j.OUT[g], j.x[g], j.gy[g], j.W1[g], j.b1[g], j.W2[g], j.gx[g], j.partials[g],
                         j.per_block[g], (int)blockIdx.x - j.wg0[g], j.wg0[g + 1] - j.wg0[g]);
+#ifdef PINGS_MLP_STATS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_mlp_clock[0] = __builtin_readcyclecounter() - c0_;
+    g_mlp_clock[1] = wall_clock64() - w0_;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- backward of the SDF decoder shape: HID = 64, OUT = 1
@@ -1395,6 +1714,13 @@ PINGS_API int pings_debug_mlp_stats(unsigned long long* out8, int reset) {
   }
   return PINGS_OK;
 }
+// out2 = {shader-clock cycles, 100 MHz real-time ticks} of workgroup 0 of the last grouped backward launch: the clock
+// the kernel really ran at = 100 MHz x out2[0] / out2[1]
+PINGS_API int pings_debug_mlp_clock(unsigned long long* out2) {
+  PINGS_HIP_CHECK(hipDeviceSynchronize());
+  PINGS_HIP_CHECK(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_mlp_clock), 16));
+  return PINGS_OK;
+}
 #endif
 
 // ---------------------------------------------------------------- grouped launches (several decoders, same rows)
@@ -1463,7 +1789,14 @@ PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, i
   pings::prof::Scope ps("mlp_bwd", st);
   // one resident workgroup per CU over all jobs together (see the forward), split between the jobs in proportion to
   // their MFMAs per tile: 4 x (17 + OH + 16 + 32), OH = k-steps of product B (mlp_bwd_wave_dispatch)
-  const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
+  // PINGS_MLP_BWD_WAVES = 2: the two-waves-per-SIMD kernel (mlp_bwd_wave2_body).  Measured equal to the default
+  // one-wave kernel at every size (125k points: 0.255 vs 0.247 ms; slope 1.70 vs 1.71 us per 1000 points) — both sit at
+  // ~83 % of the matrix pipe at the clock the launch really runs at (2.1-2.2 GHz by s_memtime / s_memrealtime, not the
+  // data sheet's 2.4) — so the default stays the kernel whose partials are bit-identical to the single launches.
+  const char* wenv = getenv("PINGS_MLP_BWD_WAVES");
+  const int wps = wenv && atoi(wenv) == 2 ? 2 : 1;
+  const int wpw = 4 * wps;   // waves per workgroup
+  const long long ntiles = (N + TR - 1) / TR, want = (ntiles + wpw - 1) / wpw;
   int cost[MAX_JOBS];
   for (int g = 0; g < njobs; ++g) {
     const bool vecg = (J.OUT[g] % 4 == 0) && ((reinterpret_cast<uintptr_t>(J.gy[g]) & 15) == 0);
@@ -1480,7 +1813,7 @@ PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, i
     int worst = -1;
     long long worst_t = -1;
     for (int g = 0; g < njobs; ++g) {
-      const long long t_g = ((ntiles + 4LL * share[g] - 1) / (4LL * share[g])) * cost[g];
+      const long long t_g = ((ntiles + (long long)wpw * share[g] - 1) / ((long long)wpw * share[g])) * cost[g];
       if (t_g > worst_t) { worst_t = t_g; worst = g; }
     }
     if (share[worst] >= want) break;      // one tile per wave already: more workgroups would idle
@@ -1489,7 +1822,10 @@ PINGS_API int pings_mlp_backward_grouped(const pings_mlp_job* jobs, int njobs, i
   J.wg0[0] = 0;
   for (int g = 0; g < njobs; ++g) J.wg0[g + 1] = J.wg0[g] + share[g];
   const int grid_w = J.wg0[njobs];
-  hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, J, njobs);
+  if (wps == 2)
+    hipLaunchKernelGGL(mlp_bwd_wave2_grouped_kernel, dim3(grid_w), dim3(512), 0, st, (long long)N, J, njobs);
+  else
+    hipLaunchKernelGGL(mlp_bwd_wave_grouped_kernel, dim3(grid_w), dim3(256), 0, st, (long long)N, J, njobs);
   PINGS_LAUNCH_CHECK();
   hipLaunchKernelGGL(mlp_reduce_grouped_kernel, dim3((unsigned)pings::ceil_div<size_t>(max_pb, 256), njobs), dim3(256),
                      0, st, J, 128);

@@ -100,6 +100,36 @@ def test_grouped_decoders_equal_the_single_launches_bit_for_bit():
             assert torch.equal(a, b), i
 
 
+@pytest.mark.gpu
+def test_grouped_backward_two_waves_per_simd_kernel_matches_the_default(monkeypatch):
+    """PINGS_MLP_BWD_WAVES=2 selects mlp_bwd_wave2_grouped_kernel (eight waves per workgroup, operands read from LDS in
+    place): same products in the same k order, a workgroup's partial adds eight waves instead of four -> input
+    gradients identical bits, weight gradients to fp32 summation-order tolerance; ragged N, all five decoder shapes."""
+    from pings_amd.mlp import fused_mlp_group
+
+    g = torch.Generator().manual_seed(14)
+    N = 9000 + 13
+    geo = torch.randn(N, 32, generator=g).cuda()
+    col = torch.randn(N, 19, generator=g).cuda()
+    shapes = [(32, 24), (32, 32), (32, 24), (32, 8), (19, 24)]
+    ups = [torch.randn(N, fo, generator=g).cuda() for _, fo in shapes]
+    res = []
+    for waves in ("1", "2"):
+        monkeypatch.setenv("PINGS_MLP_BWD_WAVES", waves)
+        gg = torch.Generator().manual_seed(15)
+        ps = [tuple(torch.randn(*sh, generator=gg).cuda().requires_grad_(True)
+                    for sh in ((128, fin), (128,), (fout, 128), (fout,))) for fin, fout in shapes]
+        xs = [(col if fin == 19 else geo).clone().requires_grad_(True) for fin, _ in shapes]
+        ys = fused_mlp_group(xs, ps)
+        loss = sum((y * u).sum() for y, u in zip(ys, ups))
+        res.append(torch.autograd.grad(loss, xs + [t for p in ps for t in p]))
+    for i, (a, b) in enumerate(zip(*res)):
+        if i < len(shapes):
+            assert torch.equal(a, b), i
+        else:
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-3 * float(a.abs().max())), (i, float((a - b).abs().max()))
+
+
 class _TorchDecoder(torch.nn.Module):
     """The parts of model/decoder.py's Decoder that `sdf` touches (layers / lout / mlp / sdf / sdf_scale)."""
 

@@ -28,3 +28,7 @@ tot = float(sum(buf))
 for n, v in zip(names, buf):
     print(f"{n:26s} {v:16d}  {100.0 * v / max(tot, 1):5.1f} %")
 print(r)
+clk = (C.c_ulonglong * 2)()
+L.pings_debug_mlp_clock.argtypes = [C.POINTER(C.c_ulonglong)]
+L.pings_debug_mlp_clock(clk)
+print({"workgroup0_shader_cycles": clk[0], "realtime_ticks_100MHz": clk[1], "shader_clock_GHz": round(0.1 * clk[0] / max(clk[1], 1), 3)})
