@@ -35,7 +35,7 @@
 
 /* ABI version of this header (bumped on any signature change).  A binding compares pings_abi_version() of the
  * library it loaded with the PINGS_ABI_VERSION of the header it was written against (pings_amd/_lib.py does). */
-#define PINGS_ABI_VERSION 7
+#define PINGS_ABI_VERSION 8
 PINGS_API int pings_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). Host string. */
 PINGS_API const char* pings_last_error(void);
@@ -432,6 +432,16 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
                                  int OUT, const float* W1, const float* b1, const float* W2,
                                  void* scratch, float* dL_dx, float* dL_dW1, float* dL_db1,
                                  float* dL_dW2, float* dL_db2, void* stream);
+/* The backward of pings_mlp_backward's dL_dx output (the graph node autograd records when the mapper differentiates
+ * dS/dx once more: utils/tools.py:409-419 `get_gradient(create_graph=True)`, used at utils/mapper.py:1445-1448 and
+ * utils/tracker.py:317).  ddx[N,IN] = cotangent of dL_dx; outputs: d_dy[N,OUT] (cotangent of dL_dy), d_W1[HID,IN],
+ * d_W2[OUT,HID]; nothing reaches x or b1 (piecewise-constant ReLU mask).  Shapes: HID = 64, OUT = 1 (`Decoder.sdf`,
+ * model/decoder.py:100-104); _supported() says so, anything else is PINGS_ERR_ARG and the host wrapper composes the
+ * node from device operators instead.  scratch: pings_mlp_backward_scratch_bytes(IN, HID, OUT). */
+PINGS_API int pings_mlp_double_backward_supported(int IN, int HID, int OUT);
+PINGS_API int pings_mlp_double_backward(const float* x, const float* ddx, const float* dL_dy, int64_t N, int IN,
+                                        int HID, int OUT, const float* W1, const float* b1, const float* W2,
+                                        void* scratch, float* d_dy, float* d_W1, float* d_W2, void* stream);
 
 /* Several decoders over the SAME N rows in one launch each way (blockIdx.y = decoder): the five spawn decoders of
  * a view (gaussian_renderer/__init__.py:605-716; hidden 128, IN <= 32 — pings.py:156-160).  Results are bitwise

@@ -1501,6 +1501,148 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_wave_h64o1_kernel(long long N,
   if (tid == 0) P[nW1 + 128] = sB[128];
 }
 
+// ---------------------------------------------------------------- backward of the backward, SDF decoder shape
+// The mapper's Eikonal / consistency terms differentiate dS/dx once more (utils/tools.py:409-419 `get_gradient` with
+// create_graph=True, used at utils/mapper.py:1445-1448): the first-order backward
+//     gx[n, :] = gy[n] * sum_j m[n, j] W2[j] W1[j, :]          (m = [W1 x + b1 > 0])
+// is itself a graph node, and a loss on gx sends a cotangent a = dL/dgx [N, IN] back through it:
+//     ggy[n]    = sum_j m[n, j] W2[j] u[n, j]                  u = a W1^T
+//     gW2[j]    = sum_n gy[n] m[n, j] u[n, j]
+//     gW1[j, :] = sum_n gy[n] m[n, j] W2[j] a[n, :]
+// (nothing reaches x or b1: the mask is piecewise constant, as in torch's own relu).  Same wave-per-tile scheme and
+// accumulator layouts as mlp_bwd_wave_h64o1_kernel: product A twice (x for the mask, a for u, sharing the W1
+// fragments), the elementwise part in the accumulator layout, gH2^T = (m W2 gy)^T through the wave's private LDS
+// tile for gW1 += gH2^T a.  Partials in the layout of the first-order kernel ([64 IN | gW2 64 | 64 zeros | 0]) so
+// that mlp_reduce_kernel sums them.
+template <int NS, int IB>
+__global__ __launch_bounds__(256, 1) void mlp_dbl_wave_h64o1_kernel(long long N, int IN, const float* __restrict__ x,
+                                                                    const float* __restrict__ a,
+                                                                    const float* __restrict__ gy,
+                                                                    const float* __restrict__ W1,
+                                                                    const float* __restrict__ b1,
+                                                                    const float* __restrict__ W2,
+                                                                    float* __restrict__ ggy,
+                                                                    float* __restrict__ partials, size_t per_block) {
+  constexpr int WI = 32 * IB;
+  constexpr int LD1 = WI | 1;
+  __shared__ float sW1[64 * LD1];          // W1[hid][i], zero beyond IN; reused for the workgroup's gW1
+  __shared__ float sG[4][32 * BW_LD];      // per wave: gH2^T as [hid_local][row]
+  __shared__ float sB[64];                 // workgroup sum of gW2
+  __shared__ float sW2[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = tid; e < 64 * WI; e += 256) {
+    const int j = e / WI, i = e - j * WI;
+    sW1[j * LD1 + i] = i < IN ? W1[(size_t)j * IN + i] : 0.f;
+  }
+  if (tid < 64) sW2[tid] = W2[tid];
+  float b1f[2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) b1f[hb] = h == 0 ? b1[hb * 32 + r] : 0.f;
+  __syncthreads();
+
+  f32x16 aW1[2][IB];
+  float aW2[2][16];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      aW2[hb][q] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) aW1[hb][ib][q] = 0.f;
+    }
+  float* myG = &sG[wave][0];
+  const long long ntiles = (N + 31) / 32;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const float one = h == 0 ? 1.f : 0.f;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += nwaves) {
+    asm volatile("" ::: "memory");  // keep the loop-invariant LDS operands in LDS (as in the first-order kernel)
+    const long long row = t * 32 + r;
+    const bool ok = row < N;
+    float xf[NS], af[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const bool in = ok && 2 * s2 + h < IN;
+      xf[s2] = in ? x[(size_t)row * IN + 2 * s2 + h] : 0.f;
+      af[s2] = in ? a[(size_t)row * IN + 2 * s2 + h] : 0.f;
+    }
+    const float gyr = ok ? gy[row] : 0.f;
+    float acol[IB][16];  // a[row = 16 h + s][column = 32 ib + r]
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const long long rc = t * 32 + 16 * h + s2;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+        acol[ib][s2] = (rc < N && 32 * ib + r < IN) ? a[(size_t)rc * IN + 32 * ib + r] : 0.f;
+    }
+    float ggy_part = 0.f;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      f32x16 pre = {0}, u = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const float w = sW1[(hb * 32 + r) * LD1 + 2 * s2 + h];
+        pre = mfma(w, xf[s2], pre);
+        u = mfma(w, af[s2], u);
+      }
+      pre = mfma(b1f[hb], one, pre);
+      float gH[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const bool on = pre[q] > 0.f;
+        const float w2 = sW2[hb * 32 + rowmap(q, h)];
+        gH[q] = on ? w2 * gyr : 0.f;
+        aW2[hb][q] = fmaf(on ? u[q] : 0.f, gyr, aW2[hb][q]);
+        ggy_part = fmaf(on ? w2 : 0.f, u[q], ggy_part);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) myG[rowmap(q, h) * BW_LD + r] = gH[q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float aG = myG[r * BW_LD + 16 * h + s2];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) aW1[hb][ib] = mfma(aG, acol[ib][s2], aW1[hb][ib]);
+      }
+    }
+    ggy_part += __shfl_xor(ggy_part, 32, 64);   // the two lane halves hold disjoint hidden units of the same row
+    if (ok && h == 0) ggy[row] = ggy_part;
+  }
+
+  // per-lane sums over rows -> sums over the 32 lanes that share h (hidden unit hb*32 + rowmap(q, h))
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) aW2[hb][q] += __shfl_xor(aW2[hb][q], off, 64);
+  // the four waves add theirs in wave order: gW1 into the (now dead) W1 image, gW2 into sB
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int hid = hb * 32 + rowmap(q, h);
+#pragma unroll
+          for (int ib = 0; ib < IB; ++ib) {
+            float* d1 = &sW1[hid * LD1 + 32 * ib + r];
+            if (w == 0) *d1 = aW1[hb][ib][q]; else *d1 += aW1[hb][ib][q];
+          }
+          if (r == 0) { if (w == 0) sB[hid] = aW2[hb][q]; else sB[hid] += aW2[hb][q]; }
+        }
+    }
+  }
+  __syncthreads();
+  float* P = partials + (size_t)blockIdx.x * per_block;  // [64 IN | gW2 64 | 64 zeros | 0]
+  const int nW1 = 64 * IN;
+  for (int e = tid; e < nW1; e += 256) P[e] = sW1[(e / IN) * LD1 + (e % IN)];
+  if (tid < 64) { P[nW1 + tid] = sB[tid]; P[nW1 + 64 + tid] = 0.f; }
+  if (tid == 0) P[nW1 + 128] = 0.f;
+}
+
 __global__ void mlp_reduce_kernel(const float* __restrict__ partials, int nblocks, size_t per_block, int IN,
                                   int HID, int OUT, float* __restrict__ gW1, float* __restrict__ gb1,
                                   float* __restrict__ gW2, float* __restrict__ gb2) {
@@ -1700,6 +1842,46 @@ PINGS_API int pings_mlp_backward(const float* x, const float* dL_dy, int64_t N, 
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0,
                      st, reinterpret_cast<const float*>(scratch), grid, per_block, IN, HID, OUT, dL_dW1,
                      dL_db1, dL_dW2, dL_db2);
+  PINGS_LAUNCH_CHECK();
+  return PINGS_OK;
+}
+
+PINGS_API int pings_mlp_double_backward_supported(int IN, int HID, int OUT) {
+  return (HID == 64 && OUT == 1 && IN > 0 && IN <= 64) ? 1 : 0;
+}
+
+PINGS_API int pings_mlp_double_backward(const float* x, const float* ddx, const float* dL_dy, int64_t N, int IN,
+                                        int HID, int OUT, const float* W1, const float* b1, const float* W2,
+                                        void* scratch, float* d_dy, float* d_W1, float* d_W2, void* stream) {
+  if (int e = check_dims(N, IN, HID, OUT)) return e;
+  PINGS_ARG_CHECK(pings_mlp_double_backward_supported(IN, HID, OUT), "double backward: hidden 64, one output only");
+  PINGS_ARG_CHECK(W1 && b1 && W2 && d_W1 && d_W2 && scratch, "null pointer");
+  hipStream_t st = pings::as_stream(stream);
+  if (N == 0) {
+    PINGS_HIP_CHECK(hipMemsetAsync(d_W1, 0, sizeof(float) * HID * IN, st));
+    PINGS_HIP_CHECK(hipMemsetAsync(d_W2, 0, sizeof(float) * OUT * HID, st));
+    return PINGS_OK;
+  }
+  PINGS_ARG_CHECK(x && ddx && dL_dy && d_dy, "null pointer");
+  const size_t per_block = partial_floats(IN, HID, OUT);
+  const long long ntiles = (N + TR - 1) / TR, want = (ntiles + 3) / 4;
+  const int grid_w = (int)(want < 256 ? want : 256);
+  // scratch: MAX_BWD_BLOCKS partials (pings_mlp_backward_scratch_bytes), then 65 floats that take the reduce kernel's
+  // (all-zero) gb1 / gb2 columns
+  float* part = reinterpret_cast<float*>(scratch);
+  float* dummy = part + (size_t)MAX_BWD_BLOCKS * per_block - 72;   // the launch uses at most 256 of the 1024 partials
+  pings::prof::Scope ps("mlp_dbl", st);
+#define PINGS_DBL(NS_, IB_)                                                                                     \
+  hipLaunchKernelGGL((mlp_dbl_wave_h64o1_kernel<NS_, IB_>), dim3(grid_w), dim3(256), 0, st, (long long)N, IN, x,  \
+                     ddx, dL_dy, W1, b1, W2, d_dy, part, per_block)
+  if (IN <= 12) PINGS_DBL(6, 1);
+  else if (IN <= 32) PINGS_DBL(16, 1);
+  else if (IN <= 36) PINGS_DBL(18, 2);
+  else PINGS_DBL(32, 2);
+#undef PINGS_DBL
+  PINGS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)pings::ceil_div<size_t>(per_block, 256)), dim3(256), 0, st,
+                     (const float*)part, grid_w, per_block, IN, HID, OUT, d_W1, dummy, d_W2, dummy + 64);
   PINGS_LAUNCH_CHECK();
   return PINGS_OK;
 }

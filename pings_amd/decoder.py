@@ -73,7 +73,8 @@ def sdf(decoder, features: torch.Tensor) -> torch.Tensor:
     """`Decoder.sdf(features)` (model/decoder.py:100-104): `mlp(features).squeeze(1) * sdf_scale` for [N, IN] or
     [N, K, IN] inputs — the decoder call of the mapper's training / inference loops (utils/mapper.py:537,574,858,1508,
     2275) — through the fused MFMA kernel pair.  First-order backward in HIP; a recorded backward (create_graph=True,
-    only taken with `numerical_grad: False`) falls to torch ops inside `_FusedMLP.backward`."""
+    only taken with `numerical_grad: False`) is the graph node `mlp._FusedMLPBackward`, whose own backward is
+    `pings_mlp_double_backward` (csrc/mlp.hip) for this decoder shape."""
     if not features.is_cuda:
         from . import _lib
 

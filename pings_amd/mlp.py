@@ -29,6 +29,10 @@ def _declare(L):
     L.pings_mlp_forward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pings_mlp_backward.restype = C.c_int
     L.pings_mlp_backward.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pings_mlp_double_backward_supported.restype = C.c_int
+    L.pings_mlp_double_backward_supported.argtypes = [i32, i32, i32]
+    L.pings_mlp_double_backward.restype = C.c_int
+    L.pings_mlp_double_backward.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pings_mlp_forward_grouped.restype = C.c_int
     L.pings_mlp_forward_grouped.argtypes = [C.POINTER(_CJob), i32, i64, vp]
     L.pings_mlp_forward_grouped_dyn.restype = C.c_int
@@ -49,10 +53,88 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
 
 
+def _hip_backward(x, W1, b1, W2, gy, need_x):
+    """`pings_mlp_backward` on detached fp32 views: (gx or None, gW1, gb1, gW2, gb2)."""
+    L = _lib.lib()
+    _declare(L)
+    xs, W1c, b1c, W2c = _f32c(x), _f32c(W1), _f32c(b1), _f32c(W2)
+    N, IN = xs.shape
+    HID, OUT = W1c.shape[0], W2c.shape[0]
+    g = _f32c(gy)
+    dev = xs.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    gx = torch.empty(N, IN, **f32) if need_x else None
+    gW1, gb1 = torch.empty(HID, IN, **f32), torch.empty(HID, **f32)
+    gW2, gb2 = torch.empty(OUT, HID, **f32), torch.empty(OUT, **f32)
+    scratch = torch.empty(L.pings_mlp_backward_scratch_bytes(IN, HID, OUT), dtype=torch.uint8, device=dev)
+    st = L.pings_mlp_backward(_lib.ptr(xs), _lib.ptr(g), N, IN, HID, OUT, _lib.ptr(W1c), _lib.ptr(b1c),
+                              _lib.ptr(W2c), _lib.ptr(scratch), _lib.ptr(gx), _lib.ptr(gW1), _lib.ptr(gb1),
+                              _lib.ptr(gW2), _lib.ptr(gb2), _lib.stream_ptr(dev))
+    _lib.check(st, "pings_mlp_backward")
+    return gx, gW1, gb1, gW2, gb2
+
+
+def _torch_backward(x, W1, b1, W2, gy, need_x):
+    """The same five gradients from device operators on the ORIGINAL tensors: differentiable to any order
+    (relu'' = 0, as torch's own relu)."""
+    pre = torch.nn.functional.linear(x, W1, b1)
+    mask = (pre > 0).to(pre.dtype)
+    gh = (gy @ W2) * mask
+    gx = gh @ W1 if need_x else None
+    return gx, gh.t() @ x, gh.sum(0), gy.t() @ (pre * mask), gy.sum(0)
+
+
+class _FusedMLPBackward(torch.autograd.Function):
+    """The first-order backward AS A GRAPH NODE (taken when it is being recorded: create_graph=True, the Eikonal /
+    consistency terms on dS/dx — utils/tools.py:409-419 `get_gradient`, utils/mapper.py:1445-1448): forward =
+    `pings_mlp_backward`; its own backward, for the one cotangent those losses produce (dL/d(dL_dx)) on the SDF decoder
+    shape, = `pings_mlp_double_backward`.  Any other cotangent / shape / a third order composes device operators."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, gy, need_x):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, W1, b1, W2, gy)
+        ctx.need_x = need_x
+        gx, gW1, gb1, gW2, gb2 = _hip_backward(x, W1, b1, W2, gy, need_x)
+        return (gx if gx is not None else x.new_zeros(0)), gW1, gb1, gW2, gb2
+
+    @staticmethod
+    def backward(ctx, a, cB, cc, cD, ce):
+        x, W1, b1, W2, gy = ctx.saved_tensors
+        L = _lib.lib()
+        N, IN = x.shape
+        HID, OUT = W1.shape[0], W2.shape[0]
+        only_a = a is not None and cB is None and cc is None and cD is None and ce is None and ctx.need_x
+        if (only_a and not torch.is_grad_enabled() and N > 0
+                and L.pings_mlp_double_backward_supported(IN, HID, OUT)):
+            xs, W1c, b1c, W2c, g, ac = _f32c(x), _f32c(W1), _f32c(b1), _f32c(W2), _f32c(gy), _f32c(a)
+            dev = xs.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            d_gy = torch.empty(N, OUT, **f32)
+            d_W1, d_W2 = torch.empty(HID, IN, **f32), torch.empty(OUT, HID, **f32)
+            scratch = torch.empty(L.pings_mlp_backward_scratch_bytes(IN, HID, OUT), dtype=torch.uint8, device=dev)
+            st = L.pings_mlp_double_backward(_lib.ptr(xs), _lib.ptr(ac), _lib.ptr(g), N, IN, HID, OUT, _lib.ptr(W1c),
+                                             _lib.ptr(b1c), _lib.ptr(W2c), _lib.ptr(scratch), _lib.ptr(d_gy),
+                                             _lib.ptr(d_W1), _lib.ptr(d_W2), _lib.stream_ptr(dev))
+            _lib.check(st, "pings_mlp_double_backward")
+            return None, d_W1, None, d_W2, d_gy, None
+        # general case: differentiate the operator composition (recorded again if a third order is being built)
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) for t in (x, W1, b1, W2, gy)]
+            outs = _torch_backward(*leaves, ctx.need_x)
+            pairs = [(o, c) for o, c in zip(outs, (a if ctx.need_x else None, cB, cc, cD, ce))
+                     if o is not None and c is not None]
+            if not pairs:
+                return None, None, None, None, None, None
+            grads = torch.autograd.grad([o for o, _ in pairs], leaves, [c for _, c in pairs], allow_unused=True,
+                                        create_graph=torch.is_grad_enabled())
+        return (*grads, None)
+
+
 class _FusedMLP(torch.autograd.Function):
     """Forward and first-order backward in HIP.  A backward that is itself being recorded (create_graph=True: the
-    Eikonal / consistency terms on dS/dx, utils/mapper.py:1448) is built from torch ops on the ORIGINAL inputs instead,
-    so that autograd can differentiate it once more (relu'' = 0, as torch's own relu)."""
+    Eikonal / consistency terms on dS/dx, utils/mapper.py:1448) becomes the graph node `_FusedMLPBackward`, whose own
+    backward is a HIP kernel for the SDF decoder shape."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2):
@@ -73,27 +155,9 @@ class _FusedMLP(torch.autograd.Function):
     def backward(ctx, gy):
         x, W1, b1, W2 = ctx.saved_tensors
         if torch.is_grad_enabled():
-            pre = torch.nn.functional.linear(x, W1, b1)
-            mask = (pre > 0).to(pre.dtype)
-            gh = (gy @ W2) * mask
-            gx = gh @ W1 if ctx.need_x else None
-            return gx, gh.t() @ x, gh.sum(0), gy.t() @ (pre * mask), gy.sum(0)
-        L = _lib.lib()
-        xs, W1c, b1c, W2c = _f32c(x), _f32c(W1), _f32c(b1), _f32c(W2)
-        N, IN = xs.shape
-        HID, OUT = W1c.shape[0], W2c.shape[0]
-        g = _f32c(gy)
-        dev = xs.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        gx = torch.empty(N, IN, **f32) if ctx.need_x else None
-        gW1, gb1 = torch.empty(HID, IN, **f32), torch.empty(HID, **f32)
-        gW2, gb2 = torch.empty(OUT, HID, **f32), torch.empty(OUT, **f32)
-        scratch = torch.empty(L.pings_mlp_backward_scratch_bytes(IN, HID, OUT), dtype=torch.uint8, device=dev)
-        st = L.pings_mlp_backward(_lib.ptr(xs), _lib.ptr(g), N, IN, HID, OUT, _lib.ptr(W1c), _lib.ptr(b1c),
-                                  _lib.ptr(W2c), _lib.ptr(scratch), _lib.ptr(gx), _lib.ptr(gW1), _lib.ptr(gb1),
-                                  _lib.ptr(gW2), _lib.ptr(gb2), _lib.stream_ptr(dev))
-        _lib.check(st, "pings_mlp_backward")
-        return gx, gW1, gb1, gW2, gb2
+            gx, gW1, gb1, gW2, gb2 = _FusedMLPBackward.apply(x, W1, b1, W2, gy, ctx.need_x)
+            return (gx if ctx.need_x else None), gW1, gb1, gW2, gb2
+        return _hip_backward(x, W1, b1, W2, gy, ctx.need_x)
 
 
 def fused_mlp(x, W1, b1, W2, b2):

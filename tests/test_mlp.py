@@ -130,6 +130,52 @@ def test_grouped_backward_two_waves_per_simd_kernel_matches_the_default(monkeypa
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-3 * float(a.abs().max())), (i, float((a - b).abs().max()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4097, 35), (1000, 11), (33, 32), (2500, 64), (1, 3)])
+def test_double_backward_kernel_matches_fp64_autograd(shape, monkeypatch):
+    """`pings_mlp_double_backward` (the backward of dL/dx of the SDF decoder shape, hidden 64, one output) against
+    fp64 autograd of the same composition: an Eikonal-type loss on dS/dx (utils/tools.py:409-419, utils/mapper.py:1445-
+    1448) differentiated w.r.t. the decoder weights, and the cotangent that flows back into the upstream graph (d_dy)."""
+    from pings_amd import mlp as mlp_mod
+    from pings_amd.mlp import fused_mlp
+
+    def no_operator_composition(*_a, **_k):      # the kernel must be what runs, not the device-operator composition
+        raise AssertionError("the recorded backward fell back to torch operators")
+
+    monkeypatch.setattr(mlp_mod, "_torch_backward", no_operator_composition)
+    N, IN = shape
+    g = torch.Generator().manual_seed(N + IN)
+    x = torch.randn(N, IN, generator=g)
+    W1, b1 = torch.randn(64, IN, generator=g) / IN ** 0.5, 0.2 * torch.randn(64, generator=g)
+    W2, b2 = torch.randn(1, 64, generator=g) / 8.0, 0.2 * torch.randn(1, generator=g)
+    for _ in range(4):      # rows within rounding of the ReLU kink have no derivative to compare
+        kink = ((x.double() @ W1.double().T + b1.double()).abs() < 1e-5).any(dim=1)
+        if not kink.any():
+            break
+        x[kink] += 0.01
+    scale = torch.rand(N, generator=g) + 0.5    # a non-trivial upstream factor: gy differs per row
+
+    def eikonal(xx, p, mlp):
+        y = mlp(xx, *p).squeeze(1) * scale.to(xx)
+        gx, = torch.autograd.grad(y.sum(), xx, create_graph=True)
+        return ((gx.norm(dim=1) - 1.0) ** 2).mean() + 0.1 * y.abs().mean(), gx
+
+    ref_p = [t.double().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    xr = x.double().requires_grad_(True)
+    lr, gxr = eikonal(xr, ref_p, lambda xx, a, b, c, d: torch.relu(xx @ a.T + b) @ c.T + d)
+    gr = torch.autograd.grad(lr, ref_p + [xr], allow_unused=True)
+    hip_p = [t.cuda().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    xh = x.cuda().requires_grad_(True)
+    lh, gxh = eikonal(xh, hip_p, fused_mlp)
+    gh = torch.autograd.grad(lh, hip_p + [xh], allow_unused=True)
+    assert rel_err(lh, lr) <= 1e-5 and rel_err(gxh, gxr) <= 1e-4
+    for name, a, b in zip(["W1", "b1", "W2", "b2", "x"], gh, gr):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) <= 1e-6, name
+        else:
+            assert rel_err(a, b) <= 1e-4, name          # tolerance: north_star 1e-4 rel
+
+
 class _TorchDecoder(torch.nn.Module):
     """The parts of model/decoder.py's Decoder that `sdf` touches (layers / lout / mlp / sdf / sdf_scale)."""
 
