@@ -1007,7 +1007,50 @@ def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8,
     pr = _prof_run(L, step, max(2, steps // 4))
     groups = {"decoders_fwd": ("mlp_fwd",), "decoders_bwd": ("mlp_bwd",), "ssim": ("ssim_fwd", "ssim_bwd"),
               "image_losses": ("image_losses_fwd", "image_losses_bwd")}
+    # allocator traffic of the timed steps (a steady-state step should find every block in torch's cache: a device
+    # allocation or free per step is a hipMalloc / hipFree with its implicit device wait)
+    ms0 = torch.cuda.memory_stats(dev)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms1 = torch.cuda.memory_stats(dev)
+    allocs = {k: (ms1.get(k, 0) - ms0.get(k, 0)) / 3.0 for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    anomaly = None
+    if t * 1e3 > 3.0 * max(sum(pr.values()), 1e-3):
+        # The wall clock is several times the kernels' sum: some boxes of the pool wake a blocked host wait only on a
+        # timer tick (round 3 saw 16 ms steps; the library's own waits poll pinned memory since).  Say WHERE the time
+        # goes: each phase's issue time and the wait behind it, medians of five steps, plus the cost of an idle wait.
+        ph = {k: [] for k in ("render_issue", "render_wait", "loss_issue", "loss_wait", "backward_issue", "backward_wait")}
+        for _ in range(5):
+            for p_ in leaves:
+                p_.grad = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pkg = render(cam, None, data, decs, None, bg, view_concat_on=True, learn_color_residual=True, d2n_on=True,
+                         gs_type="gaussian_surfel")
+            t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            il = image_losses(pkg["render"], gt_rgb, pkg["surf_depth"], gt_depth, pkg["rend_alpha"], pkg["rend_normal"],
+                              pkg["surf_normal"], sky, depth_min=0.3, depth_max=80.0, depth_min_accu_alpha=0.4)
+            ssim = fused_ssim(pkg["render"].unsqueeze(0), gt_rgb.unsqueeze(0))
+            loss = 0.8 * il.rgb_l1 + 0.2 * (1.0 - ssim) + 0.5 * il.depth_l1 + 0.05 * il.normal_depth_consist + 0.1 * il.sky
+            t3 = time.perf_counter(); torch.cuda.synchronize(); t4 = time.perf_counter()
+            loss.backward()
+            t5 = time.perf_counter(); torch.cuda.synchronize(); t6 = time.perf_counter()
+            for k_, v_ in zip(ph, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+                ph[k_].append(v_ * 1e3)
+        idle = []
+        for _ in range(5):
+            t0 = time.perf_counter(); torch.cuda.synchronize(); idle.append((time.perf_counter() - t0) * 1e3)
+        tiny = torch.zeros(1, device=dev)
+        item = []
+        for _ in range(5):
+            t0 = time.perf_counter(); tiny.add_(1.0).item(); item.append((time.perf_counter() - t0) * 1e3)
+        med = lambda v: round(sorted(v)[len(v) // 2], 3)
+        anomaly = {"note": "wall > 3x the kernels' sum on this box: per-phase host times (ms, medians of 5 synchronised steps)",
+                   "phases_ms": {k_: med(v_) for k_, v_ in ph.items()}, "idle_synchronize_ms": med(idle),
+                   "one_element_item_ms": med(item)}
     return {"width": W, "height": H, "neural_points": n, "gaussians_rasterised": info["gaussians"],
+            "device_allocs_per_step": {k: round(v, 2) for k, v in allocs.items()}, "timing_anomaly": anomaly,
             "visible_neural_point_ratio": round(float(info["visible_ratio"]), 3), "ms_per_step": round(t * 1e3, 4),
             "Mpix_s": round(W * H / t / 1e6, 1), "host_syncs_per_render": syncs,
             "host_syncs_total": int(sum(syncs.values())),

@@ -364,6 +364,149 @@ __global__ __launch_bounds__(256) void ssim_fwd_sw_kernel(
   if (lane == 0) partials[unit] = local;
 }
 
+// ---------------------------------------------------------------- forward, sliding window, vertical pass first
+// ssim_fwd_sw_kernel filters every INPUT row horizontally (two images, three products per tap) and adds the five row
+// statistics into eleven pending output rows.  The two passes commute: here an input row's raw moments (a, b, a^2, b^2,
+// ab: formed once per input pixel) are added into the pending rows first, and a finished OUTPUT row takes the horizontal
+// pass — 39 rows of a 49-step band instead of 49, on five values instead of on two images x three products per tap.
+// Same strips, bands, prefetch ring and alternating band direction; the sums associate differently (fp32: ~1e-7
+// relative against the tile kernel, nothing is bit-identical to it any more).
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void ssim_fwd_vf_kernel(
+    const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
+    int bands, int alt, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+    float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63;
+  // units = (plane, band, strip), strips fastest; the four waves of a workgroup take four neighbouring strips of one
+  // band, and every XCD label (blockIdx & 7) a contiguous range of workgroups, so that the 10-column / 10-row overlaps
+  // of neighbouring units meet in one L2 (see tile_walk above)
+  const long long units = (long long)planes * bands * strips;
+  const long long nblk = gridDim.x;
+  long long blk = blockIdx.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);
+  const long long unit = blk * 4 + (threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int strip = (int)(unit % strips), band = (int)((unit / strips) % bands);
+  const size_t plane_off = (size_t)(unit / ((long long)strips * bands)) * H * W;
+  const int x = strip * SW_OUT + lane - HALO;           // this lane's input (and, for lanes 5..58, output) column
+  const bool x_in = x >= 0 && x < W;
+  // the horizontal pass below leaves the result for column x - 5 on this lane: lanes 10..63 hold the strip's 54 outputs
+  const int xo = x - HALO;
+  const bool x_out = lane >= 2 * HALO && xo < W;
+  const int yb = band * RB, ye = min(H, yb + RB);       // output rows [yb, ye)
+  // Odd bands walk bottom-up (alt): a band's last rows are then its lower neighbour's FIRST rows' neighbours in time as
+  // well as in space, so the ten halo rows two bands share are read by both within a few row steps and the second read
+  // hits the XCD's L2 (walking every band top-down, band i reads them ~RB steps after band i + 1 did: 40 us and 8 MB of
+  // other rows later — PMC: 1.23x the algorithmic bytes).  The window is symmetric, so a reversed band applies the same
+  // eleven weights; its outputs add their taps in the opposite row order (fp32 association: ~1e-7 relative).
+  const bool up = alt && (band & 1);
+  const int y_first = up ? ye + HALO - 1 : yb - HALO, y_step = up ? -1 : 1;      // input row of step t: y_first + t y_step
+  const int r_first = up ? ye + 2 * HALO - 1 : yb - 2 * HALO;                    // output row finished at step t
+  // wave-uniform plane bases and 32-bit element offsets (one plane holds fewer than 2^31 pixels): the loads and stores
+  // take the scalar-base form and the per-row address is one 32-bit multiply-add, not a 64-bit chain per access
+  const float* const p1 = img1 + plane_off;
+  const float* const p2 = img2 + plane_off;
+  const int xc = x_in ? x : 0;
+
+  constexpr int PFD = 4;     // input rows in flight ahead of the one being filtered
+  v2f rab[11];               // (img1, img2) of input row t in slot t % 11; only PFD of them are live at a time
+  // pending output rows: slot (t + 5 - k) % 11 for the row that takes tap k of input row t; (mu1, mu2), (e11, e22), e12
+  v2f accm[11], accs[11];
+  float accx[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    rab[i] = v2f{0.f, 0.f};
+    if (i < PFD) {
+      const int y = y_first + i * y_step;
+      const bool in = x_in && y >= 0 && y < H;
+      const int o = (y >= 0 && y < H ? y : 0) * W + xc;
+      const float va = p1[o], vb = p2[o];
+      rab[i] = v2f{in ? va : 0.f, in ? vb : 0.f};
+    }
+    accm[i] = v2f{0.f, 0.f}; accs[i] = v2f{0.f, 0.f}; accx[i] = 0.f;
+  }
+  float local = 0.f;
+  const int t_end = (ye - yb) + 2 * HALO;                // input rows yb - 5 .. ye + 4
+  for (int t0 = 0; t0 < t_end; t0 += 11) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int t = t0 + i;
+      if (t < t_end) {                                   // wave-uniform
+        const v2f c0 = rab[i];
+        {   // the row PFD steps ahead
+          const int y = y_first + (t + PFD) * y_step;
+          const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
+          const int o = (y >= 0 && y < H ? y : 0) * W + xc;
+          const float va = p1[o], vb = p2[o];
+          rab[(i + PFD) % 11] = v2f{in ? va : 0.f, in ? vb : 0.f};
+        }
+        // ---- vertical FIRST, on the raw moments of this input row (formed once per input pixel): the row is tap k of
+        // output row (yb - 5 + t) + 5 - k
+        const v2f sq = c0 * c0;
+        const float xy = c0.x * c0.y;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const int sl = (i + 5 - k + 11) % 11;
+          const float w = kWin[k];
+          const v2f ww = {w, w};
+          accm[sl] = __builtin_elementwise_fma(ww, c0, accm[sl]);
+          accs[sl] = __builtin_elementwise_fma(ww, sq, accs[sl]);
+          accx[sl] = fmaf(w, xy, accx[sl]);
+        }
+        // ---- the output row that just took its last tap (k = 10): r = yb - 10 + t.  Only the band's own rows take the
+        // horizontal pass (39 of the 49 steps of a 39-row band): the five column sums travel ACROSS the lanes in
+        // transposed form — acc <- shift(acc) + w_k v, one add with a DPP operand per tap, the six distinct products
+        // w_k v formed once (the window is symmetric) — 16 instructions per statistic instead of 10 moves + 11 fmas on
+        // each of two images and three products per tap.
+        const int sl = (i + 5 - 10 + 11) % 11;
+        const int r = r_first + t * y_step;
+        if (r >= yb && r < ye) {                          // wave-uniform
+          // the five chains advance in lockstep: a DPP operand may not be read within two issue slots of its write, and
+          // four other chains' adds fill them (one chain after the other cost one s_nop per add)
+          const float hv[5] = {accm[sl].x, accm[sl].y, accs[sl].x, accs[sl].y, accx[sl]};
+          float tk[5][6], hacc[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tk[j][k] = kWin[k] * hv[j];
+            hacc[j] = tk[j][0];
+          }
+#pragma unroll
+          for (int k = 1; k < 11; ++k) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) hacc[j] = dpp_wave<0x138>(hacc[j]) + tk[j][k < 6 ? k : 10 - k];
+          }
+          // lane l now holds sum_k w_k v[l - 10 + k]: the filtered values at column x - 5
+          const float mu1 = hacc[0], mu2 = hacc[1], e11 = hacc[2], e22 = hacc[3], e12 = hacc[4];
+          if (x_out) {
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
+            const float A1 = 2.f * mu12 + kC1;
+            const float A2 = 2.f * sig12 + kC2;
+            const float B1 = mu1_sq + mu2_sq + kC1;
+            const float B2 = sig1 + sig2 + kC2;
+            const float inv_B1 = __builtin_amdgcn_rcpf(B1), inv_B2 = __builtin_amdgcn_rcpf(B2);   // as ssim_fwd_sw_kernel
+            const float m = (A1 * A2) * (inv_B1 * inv_B2);
+            local += m;
+            if (TRAIN) {
+              const float d_s1 = -m * inv_B2;
+              const float d_s12 = 2.f * A1 * inv_B1 * inv_B2;
+              const float d_mu1 = 2.f * mu2 * A2 * inv_B1 * inv_B2 - 2.f * mu1 * m * inv_B1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+              const int o = r * W + xo;
+              (dm_dmu1 + plane_off)[o] = d_mu1;
+              (dm_dsigma1_sq + plane_off)[o] = d_s1;
+              (dm_dsigma12 + plane_off)[o] = d_s12;
+            }
+          }
+        }
+        accm[sl] = v2f{0.f, 0.f}; accs[sl] = v2f{0.f, 0.f}; accx[sl] = 0.f;   // the slot now belongs to output row r + 11
+      }
+    }
+  }
+  local = wave_sum(local);
+  if (lane == 0) partials[unit] = local;
+}
+
   __global__ __launch_bounds__(NT) void ssim_reduce_kernel(const float* __restrict__ partials,
                                                             size_t n, double inv_count,
                                                             float* __restrict__ out) {
@@ -591,6 +734,110 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
   }
 }
 
+// ---------------------------------------------------------------- backward, sliding window, vertical pass first
+// As ssim_fwd_vf_kernel: the three derivative maps are summed down the columns first (33 fused multiply-adds per input
+// row), a finished output row takes the horizontal pass in transposed form (3 x 16 instructions, only for the band's
+// own rows) and is completed with the two images read at the column the result lands on.
+__global__ __launch_bounds__(256) void ssim_bwd_vf_kernel(
+    const float* __restrict__ img1, const float* __restrict__ img2, int planes, int H, int W, int RB, int strips,
+    int bands, int alt, const float* __restrict__ dL_dmean, float inv_count, const float* __restrict__ dm_dmu1,
+    const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+  const int lane = threadIdx.x & 63;
+  const long long units = (long long)planes * bands * strips;
+  const long long nblk = gridDim.x;
+  long long blk = blockIdx.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);
+  const long long unit = blk * 4 + (threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int strip = (int)(unit % strips), band = (int)((unit / strips) % bands);
+  const size_t plane_off = (size_t)(unit / ((long long)strips * bands)) * H * W;
+  const int x = strip * SW_OUT + lane - HALO;
+  const bool x_in = x >= 0 && x < W;
+  const int xo = x - HALO;                                  // the horizontal pass leaves column x - 5 on this lane
+  const bool x_out = lane >= 2 * HALO && xo < W;
+  const int yb = band * RB, ye = min(H, yb + RB);
+  const bool up = alt && (band & 1);                       // odd bands bottom-up, see ssim_fwd_sw_kernel
+  const int y_first = up ? ye + HALO - 1 : yb - HALO, y_step = up ? -1 : 1;
+  const int r_first = up ? ye + 2 * HALO - 1 : yb - 2 * HALO;
+  const size_t col = plane_off + (x_in ? x : 0);
+  const size_t colo = plane_off + (x_out ? xo : 0);          // the images are read where the output is written
+  const float g = dL_dmean[0] * inv_count;
+
+  constexpr int PFD = 4;
+  float r0[11], r1[11], r2[11];   // input rows of the three maps in flight (slot t % 11), PFD live
+  float i1[11], i2[11];           // the images at the output row that completes at step t (slot t % 11), PFD live
+  v2f accab[11];                  // pending output rows: (A, B) and D, slot (t + 5 - k) % 11
+  float accd[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    r0[i] = r1[i] = r2[i] = 0.f;
+    i1[i] = i2[i] = 0.f;
+    if (i < PFD) {
+      const int y = y_first + i * y_step;
+      const bool in = x_in && y >= 0 && y < H;
+      const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
+      const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
+      r0[i] = in ? v0 : 0.f; r1[i] = in ? v1 : 0.f; r2[i] = in ? v2 : 0.f;
+      const int ro = r_first + i * y_step;                    // output row finished at step i
+      const size_t oo = colo + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
+      i1[i] = img1[oo]; i2[i] = img2[oo];
+    }
+    accab[i] = v2f{0.f, 0.f}; accd[i] = 0.f;
+  }
+  const int t_end = (ye - yb) + 2 * HALO;
+  for (int t0 = 0; t0 < t_end; t0 += 11) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int t = t0 + i;
+      if (t < t_end) {
+        const float c0 = r0[i], c1 = r1[i], c2 = r2[i];
+        const float px = i1[i], py = i2[i];
+        {   // PFD steps ahead: the maps' input row and the images' output row
+          const int y = y_first + (t + PFD) * y_step;
+          const bool in = x_in && y >= 0 && y < H && t + PFD < t_end;
+          const size_t o = col + (size_t)(y >= 0 && y < H ? y : 0) * W;
+          const float v0 = dm_dmu1[o], v1 = dm_dsigma1_sq[o], v2 = dm_dsigma12[o];
+          r0[(i + PFD) % 11] = in ? v0 : 0.f; r1[(i + PFD) % 11] = in ? v1 : 0.f; r2[(i + PFD) % 11] = in ? v2 : 0.f;
+          const int ro = r_first + (t + PFD) * y_step;
+          const size_t oo = colo + (size_t)(ro >= 0 && ro < H ? ro : 0) * W;
+          i1[(i + PFD) % 11] = img1[oo]; i2[(i + PFD) % 11] = img2[oo];
+        }
+        // ---- vertical first (see ssim_fwd_vf_kernel): the input row of the three maps is tap k of output row ... + 5 - k
+        {
+          const v2f c01 = {c0, c1};
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            const int sl = (i + 5 - k + 11) % 11;
+            const float w = kWin[k];
+            const v2f ww = {w, w};
+            accab[sl] = __builtin_elementwise_fma(ww, c01, accab[sl]);
+            accd[sl] = fmaf(w, c2, accd[sl]);
+          }
+        }
+        const int sl = (i + 5 - 10 + 11) % 11;
+        const int r = r_first + t * y_step;
+        if (r >= yb && r < ye) {                          // wave-uniform: the band's own rows take the horizontal pass
+          const float hv[3] = {accab[sl].x, accab[sl].y, accd[sl]};
+          float tk[3][6], hacc[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tk[j][k] = kWin[k] * hv[j];
+            hacc[j] = tk[j][0];
+          }
+#pragma unroll
+          for (int k = 1; k < 11; ++k) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hacc[j] = dpp_wave<0x138>(hacc[j]) + tk[j][k < 6 ? k : 10 - k];
+          }
+          if (x_out) dL_dimg1[plane_off + (size_t)r * W + xo] = g * (hacc[0] + 2.f * px * hacc[1] + py * hacc[2]);
+        }
+        accab[sl] = v2f{0.f, 0.f}; accd[sl] = 0.f;
+      }
+    }
+  }
+}
+
   }  // namespace
 
   namespace {
@@ -644,12 +891,18 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
       unsigned nblk = (unsigned)pings::ceil_div<size_t>(units, 4);
       nblk = (nblk + 7u) & ~7u;                  // a multiple of eight: the XCD-contiguous numbering above
       pings::prof::Scope ps("ssim_fwd", st);
-      if (train)
-        hipLaunchKernelGGL(ssim_fwd_sw_kernel<true>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
-                           bands, sw_alternate(), dm_dmu1, dm_dsigma1_sq, dm_dsigma12, partials);
-      else
-        hipLaunchKernelGGL(ssim_fwd_sw_kernel<false>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips,
-                           bands, sw_alternate(), (float*)nullptr, (float*)nullptr, (float*)nullptr, partials);
+      const bool hfirst = fwd_env && fwd_env[0] == 's';   // PINGS_SSIM_FWD=sw: the horizontal-first kernel (A/B runs)
+#define PINGS_SSIM_FWD_LAUNCH(K_, T_, A_, B_, C_)                                                                   \
+  hipLaunchKernelGGL(K_<T_>, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands, sw_alternate(), \
+                     A_, B_, C_, partials)
+      if (train) {
+        if (hfirst) PINGS_SSIM_FWD_LAUNCH(ssim_fwd_sw_kernel, true, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+        else PINGS_SSIM_FWD_LAUNCH(ssim_fwd_vf_kernel, true, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+      } else {
+        if (hfirst) PINGS_SSIM_FWD_LAUNCH(ssim_fwd_sw_kernel, false, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+        else PINGS_SSIM_FWD_LAUNCH(ssim_fwd_vf_kernel, false, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+      }
+#undef PINGS_SSIM_FWD_LAUNCH
       PINGS_LAUNCH_CHECK();
       const double inv_count = 1.0 / ((double)planes * H * W);
       hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), dim3(NT), 0, st, partials, units, inv_count, out_mean);
@@ -692,8 +945,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_sw_kernel(
       unsigned nblk = (unsigned)pings::ceil_div<size_t>(units, 4);
       nblk = (nblk + 7u) & ~7u;
       pings::prof::Scope ps("ssim_bwd", st);
-      hipLaunchKernelGGL(ssim_bwd_sw_kernel, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands,
-                         sw_alternate(), dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+      if (bwd_env && bwd_env[0] == 's')              // PINGS_SSIM_BWD=sw: the horizontal-first kernel (A/B runs)
+        hipLaunchKernelGGL(ssim_bwd_sw_kernel, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands,
+                           sw_alternate(), dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+      else
+        hipLaunchKernelGGL(ssim_bwd_vf_kernel, dim3(nblk), dim3(256), 0, st, img1, img2, planes, H, W, rb, strips, bands,
+                           sw_alternate(), dL_dmean, inv_count, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
       PINGS_LAUNCH_CHECK();
       return PINGS_OK;
     }

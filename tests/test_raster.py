@@ -487,14 +487,14 @@ def test_mid_size_scene_forward_and_gradients_match_oracle(kind, P, W, H, fx):
 @pytest.mark.gpu
 def test_c2_shape_gradients_match_the_oracle_on_a_tile_subset():
     """an oracle-checked GRADIENT test on the C2 shape — Replica-like room at the full 640x480 with the
-    bench's intrinsics, density reduced to 60k surfels so that the fp32 + fp64 autograd oracles finish within a minute on the GPU box's host; the
+    bench's intrinsics, density reduced to 80k surfels so that the fp32 + fp64 autograd oracles finish within a minute on the GPU box's host; the
     oracle blends a checkerboard of the 1,200 tiles (`tile_subset`) and the upstream gradients are zero on the others,
     so both sides differentiate the same loss.  Every gradient tensor under the identified-set gate, the flagged
     fraction under the room ceiling."""
     import bench
     from scenes import room_scene, scene_as_dict
 
-    P, W, H, fx = 60_000, 640, 480, 600.0
+    P, W, H, fx = 80_000, 640, 480, 600.0
     sc = scene_as_dict(*room_scene(P, device="cpu", seed=2), W, H, fx)
     sub = lambda tx, ty: (tx + ty) % 2 == 0
     gx, gy = (W + 15) // 16, (H + 15) // 16

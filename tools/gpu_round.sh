@@ -8,7 +8,7 @@ O=$R/gpurun_out/r04$tag
 mkdir -p $O
 export TMPDIR=/tmp
 if [ "$part" = "1" ]; then
-  timeout -k 10 600 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  timeout -k 10 800 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
   tail -3 $O/pytest.log
   timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"
   timeout -k 10 500 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?"

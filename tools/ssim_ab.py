@@ -15,7 +15,8 @@ g = torch.Generator(device=dev).manual_seed(1)
 a = torch.rand(1, 3, 1080, 1920, generator=g, device=dev, requires_grad=True)
 b = torch.rand(1, 3, 1080, 1920, generator=g, device=dev)
 ref = None
-for fwd, rb in (("tile", None), ("sw", None), ("sw", 20), ("sw", 24), ("sw", 28), ("sw", 32), ("sw", 40), ("sw", 64)):
+# "tile": rounds 1-3; "sw": sliding window, horizontal pass first; "vf": sliding window, vertical pass first (default)
+for fwd, rb in (("tile", None), ("sw", None), ("vf", None), ("vf", 28), ("vf", 32), ("vf", 48), ("vf", 64), ("sw", 32), ("sw", 64)):
     os.environ["PINGS_SSIM_FWD"] = fwd
     os.environ["PINGS_SSIM_BWD"] = fwd
     if rb is None:
