@@ -1010,11 +1010,18 @@ def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8,
     # allocator traffic of the timed steps (a steady-state step should find every block in torch's cache: a device
     # allocation or free per step is a hipMalloc / hipFree with its implicit device wait)
     ms0 = torch.cuda.memory_stats(dev)
+    seg0 = {sg["address"]: sg["total_size"] for sg in torch.cuda.memory_snapshot()}
     for _ in range(3):
         step()
     torch.cuda.synchronize()
     ms1 = torch.cuda.memory_stats(dev)
+    seg1 = {sg["address"]: sg["total_size"] for sg in torch.cuda.memory_snapshot()}
     allocs = {k: (ms1.get(k, 0) - ms0.get(k, 0)) / 3.0 for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    allocs["reserved_MB_delta_per_step"] = (ms1.get("reserved_bytes.all.current", 0) - ms0.get("reserved_bytes.all.current", 0)) / 3.0 / 2**20
+    allocs["active_MB_delta_per_step"] = (ms1.get("active_bytes.all.current", 0) - ms0.get("active_bytes.all.current", 0)) / 3.0 / 2**20
+    new_segs = sorted((sz for a_, sz in seg1.items() if a_ not in seg0), reverse=True)
+    allocs["new_segments_in_3_steps"] = len(new_segs)
+    allocs["largest_new_segment_MB"] = (new_segs[0] / 2**20) if new_segs else 0.0
     anomaly = None
     if t * 1e3 > 3.0 * max(sum(pr.values()), 1e-3):
         # The wall clock is several times the kernels' sum: some boxes of the pool wake a blocked host wait only on a
@@ -1050,7 +1057,7 @@ def bench_render_step(dev, steps, warmup, W=1920, H=1080, n_points=160_000, K=8,
                    "phases_ms": {k_: med(v_) for k_, v_ in ph.items()}, "idle_synchronize_ms": med(idle),
                    "one_element_item_ms": med(item)}
     return {"width": W, "height": H, "neural_points": n, "gaussians_rasterised": info["gaussians"],
-            "device_allocs_per_step": {k: round(v, 2) for k, v in allocs.items()}, "timing_anomaly": anomaly,
+            "device_allocs_per_step": {k: round(float(v), 2) for k, v in allocs.items()}, "timing_anomaly": anomaly,
             "visible_neural_point_ratio": round(float(info["visible_ratio"]), 3), "ms_per_step": round(t * 1e3, 4),
             "Mpix_s": round(W * H / t / 1e6, 1), "host_syncs_per_render": syncs,
             "host_syncs_total": int(sum(syncs.values())),

@@ -268,9 +268,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         # divides the returned depth in place (gaussian_renderer/__init__.py:430), which a saved
         # tensor's version check would reject; the 3DGS backward never reads that depth, and the
         # surfel caller does not edit its (already normalised) depth.
+        # What is RETURNED are aliases (same storage, fresh tensor objects): the returned object is the one that gets this
+        # node as its grad_fn, and the node owns ctx -> fs -> the image tensors — returning fs's own objects closed a
+        # reference cycle (output -> grad_fn -> ctx -> fs -> output) that only Python's cycle collector could free:
+        # every frame's images, binning and geometry blocks stayed allocated until the next collection (measured in
+        # bench.py's render_step leg: +530 MB and ten hipMalloc calls per step).
         if prep.mode == MODE_SURFEL:
-            return fs.color, fs.normal, fs.depth, fs.alpha, radii, per_g
-        return fs.color, radii, fs.depth, fs.alpha, per_g
+            return fs.color.detach(), fs.normal.detach(), fs.depth.detach(), fs.alpha.detach(), radii, per_g
+        return fs.color.detach(), radii, fs.depth.detach(), fs.alpha.detach(), per_g
 
     @staticmethod
     def backward(ctx, *grads):

@@ -186,7 +186,10 @@ class _SpawnRaster(torch.autograd.Function):
         else:
             radii_o, per_g_o = radii[:count], per_g[:count]
         nsk = n_sel * k
-        outs = (o_color, o_normal, o_depth, o_alpha, radii_o, per_g_o, xyz[:count], scale[:count], rot[:count],
+        # the four images are returned as ALIASES of the tensors ctx.keep holds (see rasterizer._RasterizeGaussians:
+        # output -> grad_fn -> ctx -> the same output object is a reference cycle only the cycle collector frees)
+        alias = lambda t: None if t is None else t.detach()
+        outs = (alias(o_color), alias(o_normal), alias(o_depth), alias(o_alpha), radii_o, per_g_o, xyz[:count], scale[:count], rot[:count],
                 alpha[:count], color[:count], alpha_all[:nsk], gfree[:count] if gfree is not None else None)
         ctx.mark_non_differentiable(*[o for o in (radii_o, per_g_o, outs[12]) if o is not None])
         ctx.set_materialize_grads(False)

@@ -10,4 +10,4 @@ import bench
 
 torch.autograd.set_multithreading_enabled(False)
 r = bench.bench_render_step(torch.device("cuda"), 20, 3)
-print(json.dumps({k: r[k] for k in ("ms_per_step", "stage_ms_sum", "stage_ms")}))
+print(json.dumps({k: r[k] for k in ("ms_per_step", "stage_ms_sum", "device_allocs_per_step", "timing_anomaly", "stage_ms")}))
