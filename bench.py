@@ -707,6 +707,23 @@ def sdf_train_rates(npm, dec, x, steps, warmup):
     return r
 
 
+def _alloc_traffic(step, dev, n=3):
+    """Allocator traffic of `n` steady-state steps (torch.cuda.memory_stats deltas per step): a step that frees by
+    reference counting finds every block in torch's cache — device allocations per step mean a hipMalloc each (tens of
+    microseconds; milliseconds on some boxes) and usually a reference cycle through an autograd ctx."""
+    step()
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_stats(dev)
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    m1 = torch.cuda.memory_stats(dev)
+    d = lambda k: (m1.get(k, 0) - m0.get(k, 0)) / float(n)
+    return {"num_device_alloc": round(d("num_device_alloc"), 2), "num_device_free": round(d("num_device_free"), 2),
+            "active_MB_delta": round(d("active_bytes.all.current") / 2**20, 2),
+            "reserved_MB_delta": round(d("reserved_bytes.all.current") / 2**20, 2)}
+
+
 def bench_sdf_step(npm, dec, dev, steps, warmup, B, with_adam=True):
     """One iteration of the SDF mapping loop exactly as an unmodified mapper runs it (utils/mapper.py:822-905 with the
     shipped defaults, utils/config.py:170-181: BCE main loss, numerical Eikonal gradient on every 10th sample inside the
@@ -766,6 +783,7 @@ def bench_sdf_step(npm, dec, dev, steps, warmup, B, with_adam=True):
     try:
         t_nb = _timeit(lambda: iteration(False), steps, warmup)
         pr = _prof_run(L, lambda: iteration(False), max(2, steps // 4))
+        out["device_allocs_per_iteration"] = _alloc_traffic(lambda: iteration(False), dev)
         out.update({"ms_per_iteration": round(t_nb * 1e3, 4), "Msamples_s": round(B / t_nb / 1e6, 2),
                     "eikonal_samples": info["eikonal_samples"], "shifted_queries": 6 * info["eikonal_samples"],
                     "stage_ms": {k: round(v, 4) for k, v in sorted(pr.items(), key=lambda kv: -kv[1])},

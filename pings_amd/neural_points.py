@@ -513,7 +513,10 @@ class _QueryFeature(torch.autograd.Function):
         if cert is not None:
             ctx.mark_non_differentiable(cert)
         ctx.set_materialize_grads(False)
-        return geo, col, w.unsqueeze(-1), cnt, cert
+        # aliases of the buffers the state keeps (st.geo_buf / st.col_buf): returning the state's own tensor objects
+        # closes the cycle output -> grad_fn -> ctx -> st -> output, which only the cycle collector frees
+        alias = lambda t: None if t is None else t.detach()
+        return alias(geo), alias(col), w.unsqueeze(-1), cnt, cert
 
     @staticmethod
     def backward(ctx, g_geo, g_col, g_w, _g_cnt, _g_cert):
@@ -661,7 +664,7 @@ class _QfRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tab, st: _QfState, which: int):
         ctx.st, ctx.which = st, which
-        return st.col_buf if which else st.geo_buf
+        return (st.col_buf if which else st.geo_buf).detach()     # an alias: see _QueryFeature.forward
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -678,7 +681,7 @@ class _QfInterleave(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, n, buf):
         ctx.F = feat.shape[-1]
-        return buf
+        return buf.detach()     # an alias: `buf` is the state's own tensor, and the state hangs off _QfGeom's ctx
 
     @staticmethod
     def backward(ctx, g):

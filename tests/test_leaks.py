@@ -123,3 +123,48 @@ def test_decoder_ssim_and_sdf_nodes_free_by_refcount():
         (1.0 - fused_ssim(a, b)).backward()
 
     _stable_after(step)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted_first", [False, True])
+def test_sdf_training_paths_free_by_refcount(weighted_first):
+    """The mapper's SDF iteration (`query_feature` + `Decoder.sdf` + numerical Eikonal gradient, utils/mapper.py:822-905)
+    and the fused `Mapper.sdf` path with its recorded backward: allocated bytes do not grow with the collector off."""
+    import bench
+    from types import SimpleNamespace as NS
+
+    from pings_amd import decoder as hdec, mapper_ops as hmap, neural_points as hnp
+
+    dev = torch.device("cuda")
+    npm, dec = bench.sdf_synth_map(100_000, dev, weighted_first=weighted_first)
+    cfg = NS(weighted_first=weighted_first, color_on=False, semantic_on=False, numerical_grad=True, gradient_decimation=10,
+             voxel_size_m=float(npm.resolution), num_grad_step_ratio=0.2)
+    feats = torch.nn.Parameter(npm.local_geo_features.detach().clone())
+    keep = npm.local_geo_features
+    npm.local_geo_features = feats
+    P_ = [torch.nn.Parameter(t.detach().clone()) for t in (dec.layers[0].weight, dec.layers[0].bias, dec.lout.weight, dec.lout.bias)]
+    dec_t = NS(layers=[NS(weight=P_[0], bias=P_[1])], lout=NS(weight=P_[2], bias=P_[3]), sdf_scale=dec.sdf_scale,
+               use_leaky_relu=False)
+    mapper = NS(neural_points=npm, sdf_mlp=dec_t, config=cfg, dtype=torch.float32, device=dev)
+    coord = bench.sdf_queries(npm, 4096, dev, seed=3)
+    ts = torch.zeros(4096, dtype=torch.int32, device=dev)
+
+    def step():
+        for p in [feats] + P_:
+            p.grad = None
+        geo, _, w, _, _ = hnp.query_feature(npm, coord, ts, query_color_feature=False)
+        s = hdec.sdf(dec_t, geo)
+        if not weighted_first:
+            s = torch.sum(s * w, dim=1).squeeze(1)                        # utils/mapper.py:861
+        grad = hmap.get_numerical_gradient(mapper, coord[::10], s[::10], 0.05)
+        (s.abs().mean() + 0.5 * ((grad.norm(2, dim=-1) - 1.0) ** 2).mean()).backward()
+        # the fused path, with the analytic gradient recorded (consistency / Eikonal on dS/dx)
+        x = coord[:1024].clone().requires_grad_(True)
+        sd, _ = hnp.sdf_train(npm, dec_t, x)
+        gx, = torch.autograd.grad(sd.sum(), x, create_graph=True)
+        (sd.abs().mean() + ((gx.norm(dim=1) - 1.0) ** 2).mean()).backward()
+
+    try:
+        _stable_after(step)
+    finally:
+        npm.local_geo_features = keep
