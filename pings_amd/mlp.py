@@ -184,9 +184,8 @@ class _FusedMLPGroup(torch.autograd.Function):
     def forward(ctx, J, fc, *args):
         L = _lib.lib()
         _declare(L)
-        f = lambda t: t.detach().to(torch.float32).contiguous()
-        xs = [f(t) for t in args[:J]]
-        ps = [f(t) for t in args[J:]]
+        xs = [_f32c(t) for t in args[:J]]      # (detach only: the shipped decoders are fp32 and contiguous already)
+        ps = [_f32c(t) for t in args[J:]]
         N = xs[0].shape[0]
         dev = xs[0].device
         jobs = (_CJob * J)()
