@@ -707,6 +707,28 @@ def sdf_train_rates(npm, dec, x, steps, warmup):
     return r
 
 
+def _malloc_probe(dev, mb=64, n=3):
+    try:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        t_a, t_f = [], []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            x = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+            x[:1] = 0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            del x
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            t_a.append((t1 - t0) * 1e3)
+            t_f.append((t2 - t1) * 1e3)
+        return {"MB": mb, "alloc_ms": round(sorted(t_a)[n // 2], 3), "free_ms": round(sorted(t_f)[n // 2], 3)}
+    except Exception as e:      # never let a probe take the line down
+        return {"error": repr(e)}
+
+
 def _alloc_traffic(step, dev, n=3):
     """Allocator traffic of `n` steady-state steps (torch.cuda.memory_stats deltas per step): a step that frees by
     reference counting finds every block in torch's cache — device allocations per step mean a hipMalloc each (tens of
@@ -1484,6 +1506,10 @@ def main():
             # False = torch.autograd.set_multithreading_enabled(False), see the top of main()
             "autograd_multithreading": os.environ.get("PINGS_BENCH_AUTOGRAD_MT", "0") == "1",
             "hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"),   # see the top of this file
+            # what a device allocation costs on THIS box (hipMalloc + first use / hipFree of 64 MB through torch, cache
+            # emptied first): the map-maintenance leg allocates while the map grows, and any step that misses torch's cache
+            # pays this per block (20 ms render steps on a box where it is milliseconds)
+            "device_malloc_probe": _malloc_probe(dev),
             "secondary_legs_timing": "best of 3 runs of `steps` calls (bench._timeit); the headline is one run of K steps",
             "host_issue_ms_per_step": {"min": round(min(host_ms), 3), "median": round(sorted(host_ms)[len(host_ms) // 2], 3),
                                        "max": round(max(host_ms), 3)},

@@ -27,8 +27,13 @@ def _stable_after(step, slack_bytes=0):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("syncs", ["one", "legacy"])
 @pytest.mark.parametrize("gs_type", ["gaussian_surfel", "3d_gs"])
-def test_render_step_frees_by_refcount(gs_type):
+def test_render_step_frees_by_refcount(gs_type, syncs, monkeypatch):
+    from pings_amd import renderer as _renderer
+
+    # "legacy" = round 2's path: spawn activations and the rasteriser as separate nodes (PINGS_RENDER_SYNCS=legacy)
+    monkeypatch.setattr(_renderer, "ONE_SYNC", syncs == "one")
     from pings_amd.image_losses import image_losses
     from pings_amd.renderer import render
     from pings_amd.ssim import fused_ssim
