@@ -60,7 +60,7 @@ def test_depth2normal_hip_matches_reference(golden_dir, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("size", [(37, 53), (1, 9), (64, 64), (270, 481)])
-def test_depth2normal_hip_forward_backward_vs_oracle(size):
+def test_depth2normal_hip_forward_backward_vs_oracle(size, monkeypatch):
     """Random depth with holes in the visibility mask, alpha weighting, odd sizes: forward and the gradient w.r.t. the
     depth against the fp64 autograd of the oracle (tolerance 1e-4 rel, north_star)."""
     from pings_amd.renderer import depth2normal as d2n_hip
@@ -85,6 +85,11 @@ def test_depth2normal_hip_forward_backward_vs_oracle(size):
     (g_hip2,) = torch.autograd.grad((d2n_hip(d_hip, mask.cuda(), cam, 1, weight=alpha.float().cuda())
                                      * gout.float().cuda()).sum(), d_hip)
     assert torch.equal(g_hip, g_hip2)
+    # the fused backward kernel (default) and the two-pass form through the scratch image: identical bits
+    monkeypatch.setenv("PINGS_D2N_BWD", "2pass")
+    (g_2p,) = torch.autograd.grad((d2n_hip(d_hip, mask.cuda(), cam, 1, weight=alpha.float().cuda())
+                                   * gout.float().cuda()).sum(), d_hip)
+    assert torch.equal(g_hip, g_2p)
 
 
 def depthnormal_oracle(depth, mask, cam):
