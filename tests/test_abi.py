@@ -37,3 +37,22 @@ def test_a_library_of_another_abi_version_is_refused(monkeypatch):
         _lib.lib()
     monkeypatch.undo()
     assert _lib.lib().pings_abi_version() == _lib.expected_abi()
+
+
+def test_double_backward_entry_rejects_other_shapes_before_any_gpu_work():
+    """`pings_mlp_double_backward` covers the SDF decoder shape (hidden 64, one output); anything else is a status code
+    (the host wrapper then composes the node from device operators), decided before a single HIP call."""
+    L = _lib.lib()
+    L.pings_mlp_double_backward_supported.restype = ctypes.c_int
+    L.pings_mlp_double_backward_supported.argtypes = [ctypes.c_int] * 3
+    assert L.pings_mlp_double_backward_supported(35, 64, 1) == 1
+    assert L.pings_mlp_double_backward_supported(11, 64, 1) == 1
+    assert L.pings_mlp_double_backward_supported(32, 128, 24) == 0
+    assert L.pings_mlp_double_backward_supported(35, 64, 3) == 0
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    L.pings_mlp_double_backward.restype = ctypes.c_int
+    L.pings_mlp_double_backward.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    st = L.pings_mlp_double_backward(None, None, None, 10, 32, 128, 24, None, None, None, None, None, None, None, None)
+    assert st == 1 and b"double backward" in L.pings_last_error()
+    st = L.pings_mlp_double_backward(None, None, None, 10, 35, 64, 1, None, None, None, None, None, None, None, None)
+    assert st == 1 and b"null" in L.pings_last_error()
